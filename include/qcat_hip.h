@@ -1,0 +1,231 @@
+/*
+ * qcat_hip.h -- C ABI of the MI355X-native barcode-demultiplexing hot path.
+ *
+ * This is the drop-in boundary.  The reference crosses exactly one
+ * process->native boundary on this path: one ctypes call into parasail per alignment
+ *   qcat/scanner_base.py:214-218   parasail_sg(s1=window, s2=template, open, extend, matrix)
+ *   qcat/scanner_base.py:111-117   parasail_sg(s1=region, s2=ctx+barcode+ctx, 1, 1, matrix_barcode)
+ * 28..244 times per read, driven by the Python of
+ *   qcat/scanner_base.py:521-604   BarcodeScanner.detect_barcode
+ *   qcat/scanner_epi2me.py:33-144  BarcodeScannerEPI2ME.scan
+ *   qcat/scanner_dual.py:35-146    BarcodeScannerDual.scan
+ * The native library replaces that whole stack with ONE call per batch of reads: the caller
+ * hands over the reads of a batch and a kit descriptor, and gets back one 24-byte record per
+ * read holding everything `detect_barcode` returns (as indices into the kit).  Each entry
+ * point below cites the reference interface it stands in for.
+ *
+ * Conventions: plain C, caller owns every buffer, the library keeps no caller pointer after a
+ * call returns; every function returns 0 on success or a negative qcat_status, and
+ * qcat_last_error() gives the message of the last failure on the calling thread.
+ * The same descriptor/record structs are consumed by the CPU oracle (oracle/qcat_oracle.c),
+ * which is test infrastructure and not part of this library.
+ */
+#ifndef QCAT_HIP_H
+#define QCAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QCAT_ABI_VERSION 1
+
+/* Base code space shared by host and device (qcat_amd/codes.py): parasail's mapper sends the
+ * alphabet letters (either case) to their index and everything else to the '*' row
+ * (SURVEY.md 8a R1); both qcat matrices are over ATGCN(+X) -- qcat/config.py:26,245. */
+enum { QCAT_CODE_A = 0, QCAT_CODE_T = 1, QCAT_CODE_G = 2, QCAT_CODE_C = 3,
+       QCAT_CODE_N = 4, QCAT_CODE_X = 5, QCAT_CODE_OTHER = 6, QCAT_CODE_PAD = 7,
+       QCAT_NCODES = 7 };
+
+enum { QCAT_MAX_TEMPLATES = 16,      /* kit auto uses 12 (qcat/scanner_base.py:444-447)   */
+       QCAT_MAX_TEMPLATE_LEN = 128,  /* longest shipped template: 102 (VMK001)            */
+       QCAT_MAX_TARGET_LEN = 64,     /* ctx + barcode + ctx; shipped: 39..46              */
+       QCAT_MAX_BARCODES = 1024,     /* per barcode set                                   */
+       QCAT_MAX_WINDOW = 160 };      /* qcatConfig.max_align_length (default 150)         */
+
+typedef enum qcat_status {
+    QCAT_OK = 0,
+    QCAT_ERR_ARG = -1,          /* bad descriptor / argument (RuntimeError on the Python side) */
+    QCAT_ERR_UNSUPPORTED = -2,  /* valid qcat configuration the device path does not cover  */
+    QCAT_ERR_DEVICE = -3,       /* HIP runtime failure / no device                           */
+    QCAT_ERR_NOMEM = -4
+} qcat_status;
+
+/* Scanner mode: which `scan()` the batch entry points reproduce. */
+typedef enum qcat_mode {
+    QCAT_MODE_EPI2ME = 0,   /* qcat/scanner_epi2me.py:33-144 */
+    QCAT_MODE_DUAL = 1      /* qcat/scanner_dual.py:35-146   */
+} qcat_mode;
+
+/* Which read ends are scanned. */
+enum { QCAT_ENDS_5P = 1,          /* scan() on the 5' window only (BASELINE config 2)        */
+       QCAT_ENDS_BOTH = 3 };      /* detect_barcode(): 5' + 3' (qcat/scanner_base.py:521-604) */
+
+/* One barcode set of one template (qcat/layout.py:176-189 get_barcode_set).
+ * `sequences` holds n * barcode_len ASCII characters, barcode b at sequences + b*barcode_len.
+ * `ids[b]` is a dense integer standing for Barcode.id -- only equality is ever used
+ * (qcat/scanner_base.py:589); the host maps YAML ids to ints. */
+typedef struct qcat_barcode_set_desc {
+    const char*    sequences;
+    const int32_t* ids;
+    int32_t        n;
+    int32_t        barcode_len;
+} qcat_barcode_set_desc;
+
+/* One adapter template = one AdapterLayout (qcat/layout.py:15-70).  Placeholder geometry is
+ * what AdapterLayout.get_placeholder_pos returns for the sets that exist (start = end = -1,
+ * len = 0 otherwise, qcat/layout.py:48-49). */
+typedef struct qcat_template_desc {
+    const char* sequence;            /* upper-case ATGCNX, N-masked (layout.py:132-145)       */
+    int32_t     length;
+    int32_t     trim_offset;         /* YAML trim_offset (adapters.py:101)                    */
+    int32_t     is_double_barcode;   /* barcode_set_2 is not None (layout.py:240-248)         */
+    int32_t     kit_slot;            /* dense index of the template's kit name (for counts)   */
+    int32_t     bc_start[2];
+    int32_t     bc_end[2];
+    int32_t     bc_len[2];
+    qcat_barcode_set_desc sets[2];   /* n == 0 <=> get_barcode_set(i) is None/empty           */
+} qcat_template_desc;
+
+/* Everything `detect_barcode` depends on besides the read. */
+typedef struct qcat_kit_desc {
+    int32_t abi_version;             /* QCAT_ABI_VERSION */
+    int32_t mode;                    /* qcat_mode */
+    int32_t ends;                    /* QCAT_ENDS_* */
+    int32_t n_templates;
+    const qcat_template_desc* templates;   /* list order = tie-break order (scanner_base.py:354) */
+    /* qcatConfig (qcat/config.py:12-21) */
+    int32_t match, nmatch;           /* used by get_norm_socre (scanner_base.py:308-310)      */
+    int32_t gap_open, gap_extend;    /* adapter alignments; barcode alignments use 1,1        */
+    int32_t max_align_length;
+    int32_t extracted_barcode_extension;
+    int32_t barcode_context_length;
+    int8_t  adapter_matrix[49];      /* [target_code*7 + query_code], config.py:236-253       */
+    int8_t  barcode_matrix[49];      /* config.py:26 (X folded onto '*')                      */
+    double  min_quality;             /* BarcodeScanner.min_quality (58 epi2me / 60 dual)      */
+    double  conflict_min_score;      /* 60 (scanner_base.py:585)                              */
+    double  region_min_adapter_score;/* 90.0 (scanner_epi2me.py:74)                           */
+    int32_t n_barcode_slots;         /* number of distinct ids over all sets (count buckets)  */
+    int32_t n_kit_slots;             /* number of distinct kit names                          */
+} qcat_kit_desc;
+
+/* Result record: the dict of qcat/scanner_base.py:381-388 as indices (24 bytes, little endian).
+ * barcode_score of the dict == raw_score * 100.0 / score_den (scanner_base.py:119), recomputed
+ * on the host so it is the same IEEE double the reference produces. */
+typedef struct qcat_result {
+    int16_t barcode_idx;    /* index into templates[adapter_idx].sets[0]; -1 = None            */
+    int16_t barcode2_idx;   /* dual mode: index into sets[1]; -1 otherwise                     */
+    int16_t adapter_idx;    /* template index; -1 = None                                       */
+    int16_t exit_status;    /* 0 / 1 / 1002 (/ 997 once scan_middle exists)                    */
+    int32_t adapter_end;
+    int32_t trim5p;
+    int32_t trim3p;
+    int16_t raw_score;      /* raw alignment score behind barcode_score (0 when None)          */
+    int16_t score_den;      /* len(upstream + barcode + downstream) it is divided by (or 1)    */
+} qcat_result;
+
+/* Per read-end trace for parity tests (qcat_scan_debug).  All values are the reference's
+ * intermediate quantities: per-template raw score / end_query of find_best_adapter_template
+ * (scanner_base.py:341-357), the chosen template, the path of scanner_epi2me.py:74-82, the
+ * slice taken by extract_barcode_region (scanner_base.py:29-60) and the arg-max of
+ * find_highest_scoring_barcode (scanner_base.py:104-134) per barcode set. */
+typedef struct qcat_end_trace {
+    int32_t window_len;
+    int32_t tpl_raw[QCAT_MAX_TEMPLATES];
+    int32_t tpl_end[QCAT_MAX_TEMPLATES];
+    int32_t best_tpl;          /* -1 if no template beat -1.0 (then the LAST template is used) */
+    int32_t best_end;
+    int32_t best_raw;
+    int32_t used_tpl;          /* template actually indexed (Python [-1] wrap applied)         */
+    int32_t region_path;       /* 1 = extract_barcode_region, 0 = whole window                 */
+    int32_t region_start[2];
+    int32_t region_len[2];
+    int32_t bc_idx[2];         /* -1 = None */
+    int32_t bc_raw[2];
+    int32_t adapter_end;       /* after trim_offset / clamp (scanner_epi2me.py:135-137)        */
+} qcat_end_trace;
+
+typedef struct qcat_kit qcat_kit;      /* immutable, shareable between contexts/threads        */
+typedef struct qcat_ctx qcat_ctx;      /* one device + stream + staging buffers; one per thread */
+typedef struct qcat_batch qcat_batch;  /* reads resident in device memory                      */
+
+const char* qcat_last_error(void);
+int  qcat_abi_version(void);
+int  qcat_device_count(void);
+
+/* replaces: BarcodeScanner.__init__ kit selection + qcatConfig (scanner_base.py:415-447). */
+int  qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out);
+void qcat_kit_destroy(qcat_kit* kit);
+/* number of int64 count buckets: [barcode slots.., none][kit slots.., none]
+ * (dual: barcode bucket = slot1 * n_barcode_slots + slot2; cli.py:366-383, scanner_base.py:680-689) */
+int  qcat_kit_count_buckets(const qcat_kit* kit);
+
+int  qcat_ctx_create(int device, qcat_ctx** out);
+void qcat_ctx_destroy(qcat_ctx* ctx);
+
+/* replaces: the per-read loop of detect_barcode_batch / cli.qcat_cli over detect_barcode
+ * (scanner_base.py:723-726, cli.py:504-513) for a fixed kit.  Host buffers in, host buffers
+ * out: `bases` = concatenated ASCII reads, read r = bases[offsets[r] .. offsets[r+1]).
+ * `counts` (optional, qcat_kit_count_buckets() entries) is ADDED to. */
+int  qcat_scan_batch(qcat_ctx* ctx, const qcat_kit* kit,
+                     const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                     qcat_result* out, int64_t* counts);
+
+/* Same, plus one qcat_end_trace per scanned read end (2*n_reads entries, 5' then 3' per read;
+ * n_reads entries with QCAT_ENDS_5P) and, if bc_rows != NULL, the raw score of EVERY barcode
+ * alignment: bc_rows[((end * 2 + set) * row_stride) + b], row_stride >= largest set. */
+int  qcat_scan_debug(qcat_ctx* ctx, const qcat_kit* kit,
+                     const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                     qcat_result* out, int64_t* counts,
+                     qcat_end_trace* traces, int16_t* bc_rows, uint32_t row_stride);
+
+/* Device-resident batches (benchmarks, pipelines that keep reads in HBM). */
+int  qcat_batch_upload(qcat_ctx* ctx, const uint8_t* bases, const uint64_t* offsets,
+                       uint32_t n_reads, qcat_batch** out);
+/* Synthetic reads generated ON the device with the stateless SplitMix64 generator of
+ * SURVEY.md 8(d) (qcat_amd/csrc/synth.h; the host twin is qcat_synth_read()). */
+typedef struct qcat_synth_params {
+    uint64_t seed;
+    uint32_t n_reads;
+    uint32_t insert_len;         /* 600 */
+    uint32_t lead_min, lead_max; /* 5..40 (also used for the tail) */
+    float    error_rate;         /* per-base, split equally sub/del/ins */
+    float    no_adapter_fraction;/* 0.05 */
+    int32_t  tpl_5p, tpl_3p;     /* template indices used to build the ends (-1: none) */
+} qcat_synth_params;
+int  qcat_batch_synthesize(qcat_ctx* ctx, const qcat_kit* kit, const qcat_synth_params* p,
+                           qcat_batch** out);
+void qcat_batch_destroy(qcat_batch* batch);
+int  qcat_batch_info(const qcat_batch* batch, uint32_t* n_reads, uint64_t* n_bases);
+/* copy a resident batch back (bases may be NULL to fetch offsets only). */
+int  qcat_batch_download(qcat_ctx* ctx, const qcat_batch* batch, uint8_t* bases, uint64_t* offsets);
+/* host twin of the device generator: writes read `index` into buf (cap bytes), returns length
+ * or a negative status. */
+int64_t qcat_synth_read(const qcat_kit* kit, const qcat_synth_params* p, uint64_t index,
+                        uint8_t* buf, uint64_t cap);
+
+/* Scan a resident batch; results and counts stay in device memory owned by ctx until the next
+ * scan.  Enqueues on the context's stream and returns without synchronising. */
+int  qcat_scan_resident(qcat_ctx* ctx, const qcat_kit* kit, const qcat_batch* batch);
+int  qcat_ctx_synchronize(qcat_ctx* ctx);
+/* copy the last scan's records / counts to the host (synchronises). */
+int  qcat_ctx_fetch_results(qcat_ctx* ctx, qcat_result* out, uint32_t n_reads);
+int  qcat_ctx_fetch_counts(qcat_ctx* ctx, int64_t* counts, int32_t n_buckets);
+/* device pointer of the last scan's int64 count vector (for an RCCL all-reduce by the caller,
+ * SURVEY.md 8e) and of the records. */
+void* qcat_ctx_counts_devptr(qcat_ctx* ctx);
+void* qcat_ctx_results_devptr(qcat_ctx* ctx);
+
+/* Kernel timing of the LAST qcat_scan_resident on this context, measured with hipEvents
+ * recorded on the context's stream around each kernel (synchronises).  names[i] points to a
+ * static string; returns the number of entries written (<= cap). */
+int  qcat_ctx_last_timing(qcat_ctx* ctx, const char** names, float* ms, int cap);
+/* enable/disable per-kernel event timing (off by default: events serialise nothing but cost
+ * a few microseconds per launch). */
+int  qcat_ctx_set_timing(qcat_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QCAT_HIP_H */

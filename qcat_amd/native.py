@@ -1,0 +1,301 @@
+"""ctypes binding of the C ABI in ``include/qcat_hip.h`` (no PyTorch, no cffi build step).
+
+``KitDescriptor`` flattens a list of :class:`~qcat_amd.layout.AdapterLayout` objects plus a
+:class:`~qcat_amd.config.qcatConfig` into the ``qcat_kit_desc`` struct; ``HipLibrary`` loads
+``libqcat_hip.so`` (built in-tree by ``__graft_entry__.build()``) and raises if it is missing --
+there is no CPU fallback on the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ABI_VERSION = 1
+MODE_EPI2ME, MODE_DUAL = 0, 1
+ENDS_5P, ENDS_BOTH = 1, 3
+MAX_TEMPLATES = 16
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libqcat_hip.so")
+
+
+class BarcodeSetDesc(C.Structure):
+    _fields_ = [("sequences", C.c_char_p), ("ids", C.POINTER(C.c_int32)),
+                ("n", C.c_int32), ("barcode_len", C.c_int32)]
+
+
+class TemplateDesc(C.Structure):
+    _fields_ = [("sequence", C.c_char_p), ("length", C.c_int32), ("trim_offset", C.c_int32),
+                ("is_double_barcode", C.c_int32), ("kit_slot", C.c_int32),
+                ("bc_start", C.c_int32 * 2), ("bc_end", C.c_int32 * 2), ("bc_len", C.c_int32 * 2),
+                ("sets", BarcodeSetDesc * 2)]
+
+
+class KitDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("mode", C.c_int32), ("ends", C.c_int32),
+                ("n_templates", C.c_int32), ("templates", C.POINTER(TemplateDesc)),
+                ("match", C.c_int32), ("nmatch", C.c_int32),
+                ("gap_open", C.c_int32), ("gap_extend", C.c_int32),
+                ("max_align_length", C.c_int32), ("extracted_barcode_extension", C.c_int32),
+                ("barcode_context_length", C.c_int32),
+                ("adapter_matrix", C.c_int8 * 49), ("barcode_matrix", C.c_int8 * 49),
+                ("min_quality", C.c_double), ("conflict_min_score", C.c_double),
+                ("region_min_adapter_score", C.c_double),
+                ("n_barcode_slots", C.c_int32), ("n_kit_slots", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("barcode_idx", C.c_int16), ("barcode2_idx", C.c_int16),
+                ("adapter_idx", C.c_int16), ("exit_status", C.c_int16),
+                ("adapter_end", C.c_int32), ("trim5p", C.c_int32), ("trim3p", C.c_int32),
+                ("raw_score", C.c_int16), ("score_den", C.c_int16)]
+
+
+RESULT_DTYPE = np.dtype([("barcode_idx", "<i2"), ("barcode2_idx", "<i2"), ("adapter_idx", "<i2"),
+                         ("exit_status", "<i2"), ("adapter_end", "<i4"), ("trim5p", "<i4"),
+                         ("trim3p", "<i4"), ("raw_score", "<i2"), ("score_den", "<i2")])
+assert RESULT_DTYPE.itemsize == 24 and C.sizeof(Result) == 24
+
+TRACE_DTYPE = np.dtype([("window_len", "<i4"), ("tpl_raw", "<i4", (MAX_TEMPLATES,)),
+                        ("tpl_end", "<i4", (MAX_TEMPLATES,)), ("best_tpl", "<i4"),
+                        ("best_end", "<i4"), ("best_raw", "<i4"), ("used_tpl", "<i4"),
+                        ("region_path", "<i4"), ("region_start", "<i4", (2,)),
+                        ("region_len", "<i4", (2,)), ("bc_idx", "<i4", (2,)),
+                        ("bc_raw", "<i4", (2,)), ("adapter_end", "<i4")])
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_reads", C.c_uint32), ("insert_len", C.c_uint32),
+                ("lead_min", C.c_uint32), ("lead_max", C.c_uint32),
+                ("error_rate", C.c_float), ("no_adapter_fraction", C.c_float),
+                ("tpl_5p", C.c_int32), ("tpl_3p", C.c_int32)]
+
+
+class KitDescriptor(object):
+    """Owns a ``qcat_kit_desc`` and every buffer it points to.
+
+    ``layouts``: list of AdapterLayout in tie-break order; ``mode``: "epi2me" | "dual";
+    ``ends``: ENDS_BOTH (detect_barcode) or ENDS_5P (scan of the 5' window only).
+    Barcode ids are mapped to dense "slots" in first-seen order (ids are only ever compared for
+    equality, qcat/scanner_base.py:589, and used as count keys, :680-689).
+    """
+
+    def __init__(self, layouts, qcat_config, mode="epi2me", min_quality=None, ends=ENDS_BOTH):
+        if mode not in ("epi2me", "dual"):
+            raise RuntimeError("Invalid demultiplexing mode: {}".format(mode))
+        if len(layouts) > MAX_TEMPLATES:
+            raise RuntimeError("too many adapter templates: {} > {}".format(len(layouts), MAX_TEMPLATES))
+        self.layouts = list(layouts)
+        self.mode = mode
+        self.ends = ends
+        if min_quality is None:
+            min_quality = 58 if mode == "epi2me" else 60
+        self.min_quality = min_quality
+        self._keep = []
+        self.id_slots = {}          # Barcode.id -> slot
+        self.slot_ids = []
+        self.kit_slots = {}
+        self.kit_names = []
+
+        tarr = (TemplateDesc * max(1, len(self.layouts)))()
+        for t, lay in enumerate(self.layouts):
+            td = tarr[t]
+            seq = lay.get_adapter_sequences().encode("ascii")
+            self._keep.append(seq)
+            td.sequence = seq
+            td.length = len(seq)
+            td.trim_offset = int(lay.trim_offset)
+            td.is_double_barcode = 1 if lay.is_double_barcode() else 0
+            if lay.kit not in self.kit_slots:
+                self.kit_slots[lay.kit] = len(self.kit_names)
+                self.kit_names.append(lay.kit)
+            td.kit_slot = self.kit_slots[lay.kit]
+            for i in (0, 1):
+                td.bc_end[i] = lay.get_barcode_end(i)
+                td.bc_len[i] = lay.get_barcode_length(i)
+                td.bc_start[i] = (lay.barcode_pos_1, lay.barcode_pos_2)[i].start
+                bset = lay.get_barcode_set(i)
+                sd = td.sets[i]
+                if not bset:
+                    sd.n = 0
+                    sd.barcode_len = 0
+                    continue
+                blob = "".join(b.sequence for b in bset).encode("latin-1", "replace")
+                ids = (C.c_int32 * len(bset))()
+                for j, b in enumerate(bset):
+                    if b.id not in self.id_slots:
+                        self.id_slots[b.id] = len(self.slot_ids)
+                        self.slot_ids.append(b.id)
+                    ids[j] = self.id_slots[b.id]
+                self._keep += [blob, ids]
+                sd.sequences = blob
+                sd.ids = ids
+                sd.n = len(bset)
+                sd.barcode_len = len(bset[0].sequence)
+        self._templates = tarr
+
+        d = KitDesc()
+        d.abi_version = ABI_VERSION
+        d.mode = MODE_DUAL if mode == "dual" else MODE_EPI2ME
+        d.ends = ends
+        d.n_templates = len(self.layouts)
+        d.templates = C.cast(tarr, C.POINTER(TemplateDesc))
+        d.match = int(qcat_config.match)
+        d.nmatch = int(qcat_config.nmatch)
+        d.gap_open = int(qcat_config.gap_open)
+        d.gap_extend = int(qcat_config.gap_extend)
+        d.max_align_length = int(qcat_config.max_align_length)
+        d.extracted_barcode_extension = int(qcat_config.extracted_barcode_extension)
+        d.barcode_context_length = int(qcat_config.barcode_context_length)
+        d.adapter_matrix[:] = [int(v) for v in qcat_config.matrix.table.reshape(-1)]
+        d.barcode_matrix[:] = [int(v) for v in qcat_config.matrix_barcode.table.reshape(-1)]
+        d.min_quality = float(min_quality)
+        d.conflict_min_score = 60.0
+        d.region_min_adapter_score = 90.0
+        d.n_barcode_slots = len(self.slot_ids)
+        d.n_kit_slots = len(self.kit_names)
+        self.desc = d
+
+    @property
+    def n_count_buckets(self):
+        nb = len(self.slot_ids)
+        return (nb * nb if self.mode == "dual" else nb) + 1 + len(self.kit_names) + 1
+
+    def byref(self):
+        return C.byref(self.desc)
+
+
+def pack_reads(read_sequences):
+    """list of str/bytes/None -> (uint8 bases, uint64 offsets[n+1])."""
+    chunks = []
+    offsets = np.zeros(len(read_sequences) + 1, dtype=np.uint64)
+    total = 0
+    for i, s in enumerate(read_sequences):
+        if s:
+            b = s.encode("latin-1", "replace") if isinstance(s, str) else bytes(s)
+            chunks.append(b)
+            total += len(b)
+        offsets[i + 1] = total
+    bases = np.frombuffer(b"".join(chunks), dtype=np.uint8) if total else np.zeros(1, dtype=np.uint8)
+    return np.ascontiguousarray(bases), offsets
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+class HipLibrary(object):
+    """Loaded ``libqcat_hip.so`` with typed entry points.  Raises RuntimeError when the library
+    is missing or a call fails (message from ``qcat_last_error``)."""
+
+    _instance = None
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "qcat_amd: native HIP library not found at {} -- run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)"
+                .format(path))
+        lib = C.CDLL(path)
+        vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+        sig = {
+            "qcat_last_error": (C.c_char_p, []),
+            "qcat_abi_version": (C.c_int, []),
+            "qcat_device_count": (C.c_int, []),
+            "qcat_kit_create": (C.c_int, [C.POINTER(KitDesc), C.POINTER(vp)]),
+            "qcat_kit_destroy": (None, [vp]),
+            "qcat_kit_count_buckets": (C.c_int, [vp]),
+            "qcat_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+            "qcat_ctx_destroy": (None, [vp]),
+            "qcat_scan_batch": (C.c_int, [vp, vp, vp, vp, u32, vp, vp]),
+            "qcat_scan_debug": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, vp, u32]),
+            "qcat_batch_upload": (C.c_int, [vp, vp, vp, u32, C.POINTER(vp)]),
+            "qcat_batch_synthesize": (C.c_int, [vp, vp, C.POINTER(SynthParams), C.POINTER(vp)]),
+            "qcat_batch_destroy": (None, [vp]),
+            "qcat_batch_info": (C.c_int, [vp, C.POINTER(u32), C.POINTER(C.c_uint64)]),
+            "qcat_batch_download": (C.c_int, [vp, vp, vp, vp]),
+            "qcat_synth_read": (C.c_int64, [vp, C.POINTER(SynthParams), C.c_uint64, vp, C.c_uint64]),
+            "qcat_scan_resident": (C.c_int, [vp, vp, vp]),
+            "qcat_ctx_synchronize": (C.c_int, [vp]),
+            "qcat_ctx_fetch_results": (C.c_int, [vp, vp, u32]),
+            "qcat_ctx_fetch_counts": (C.c_int, [vp, vp, i32]),
+            "qcat_ctx_counts_devptr": (vp, [vp]),
+            "qcat_ctx_results_devptr": (vp, [vp]),
+            "qcat_ctx_last_timing": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
+            "qcat_ctx_set_timing": (C.c_int, [vp, C.c_int]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, name)          # AttributeError here = ABI symbol missing
+            fn.restype = res
+            fn.argtypes = args
+        self.lib = lib
+        self.path = path
+        self.symbols = sorted(sig)
+
+    @classmethod
+    def get(cls):
+        if cls._instance is None:
+            cls._instance = cls()
+        return cls._instance
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.qcat_last_error()
+            raise RuntimeError("qcat_hip error {}: {}".format(rc, (msg or b"").decode("utf-8", "replace")))
+
+
+class NativeKit(object):
+    """``qcat_kit*`` handle (immutable, shareable)."""
+
+    def __init__(self, descriptor):
+        self.hip = HipLibrary.get()
+        self.descriptor = descriptor
+        h = C.c_void_p()
+        self.hip.check(self.hip.lib.qcat_kit_create(descriptor.byref(), C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.hip.lib.qcat_kit_destroy(h)
+            self.handle = None
+
+
+class NativeContext(object):
+    """``qcat_ctx*`` handle: one device, one stream; not re-entrant."""
+
+    def __init__(self, device=0):
+        self.hip = HipLibrary.get()
+        h = C.c_void_p()
+        self.hip.check(self.hip.lib.qcat_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.hip.lib.qcat_ctx_destroy(h)
+            self.handle = None
+
+    def scan(self, kit, bases, offsets, counts=None, trace=False, rows=False):
+        n = len(offsets) - 1
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        cptr = counts.ctypes.data if counts is not None else None
+        if not trace:
+            self.hip.check(self.hip.lib.qcat_scan_batch(
+                self.handle, kit.handle, bases.ctypes.data, offsets.ctypes.data, n,
+                out.ctypes.data, cptr))
+            return out
+        ends = 1 if kit.descriptor.ends == ENDS_5P else 2
+        traces = np.zeros(n * ends, dtype=TRACE_DTYPE)
+        stride = 0
+        bc_rows = None
+        if rows:
+            stride = max(len(s) for lay in kit.descriptor.layouts
+                         for s in (lay.barcode_set_1 or [], lay.barcode_set_2 or []))
+            bc_rows = np.full((n * ends, 2, stride), -32768, dtype=np.int16)
+        self.hip.check(self.hip.lib.qcat_scan_debug(
+            self.handle, kit.handle, bases.ctypes.data, offsets.ctypes.data, n,
+            out.ctypes.data, cptr, traces.ctypes.data,
+            bc_rows.ctypes.data if bc_rows is not None else None, stride))
+        return out, traces, bc_rows

@@ -1,0 +1,215 @@
+"""Host side of the drop-in boundary: ``BarcodeScanner`` with the reference's constructor
+keywords and methods (``qcat/scanner_base.py:410-733``), executing on the MI355X through the
+C ABI of ``include/qcat_hip.h``.
+
+What stays in Python is only what the reference keeps per *batch* or per *object*: kit
+selection (``:415-447``), the per-batch kit vote and low-abundance filter (``:662-733``) and
+the mapping of native index records back to ``Barcode`` / ``AdapterLayout`` objects.  All
+per-read work of ``detect_barcode`` (``:521-604``) -- windows, adapter and barcode alignments,
+thresholds, conflict detection, trims -- happens inside one native call per batch.
+"""
+import logging
+import operator
+
+import numpy as np
+
+from . import adapters, config, native
+from .adapters import Barcode
+
+
+def build_return_dict(best_barcode, best_barcode_score, best_adapter, best_adapter_end,
+                      exit_status, trim5p=0, trim3p=0):
+    """Result dictionary with the reference's keys (``qcat/scanner_base.py:381-388``)."""
+    return {"barcode": best_barcode,
+            "barcode_score": best_barcode_score,
+            "adapter": best_adapter,
+            "adapter_end": best_adapter_end,
+            "trim5p": trim5p,
+            "trim3p": trim3p,
+            "exit_status": exit_status}
+
+
+def empty_return_dict():
+    """``qcat/scanner_base.py:393-407``."""
+    return build_return_dict(None, 0.0, None, 0, 1, trim5p=0, trim3p=0)
+
+
+def extract_align_sequence(read_sequence, rev_comp, length):
+    """Window of the read that is scanned (``qcat/scanner_base.py:223-244``); kept on the host
+    for API compatibility -- the device computes the same windows itself."""
+    from .utils import revcomp
+    seq = read_sequence if read_sequence else ""
+    if length > 0:
+        seq = revcomp(seq[-length:]) if rev_comp else seq[:length]
+    return seq
+
+
+class BarcodeScanner(object):
+    """Abstract base class of the MI355X scanners (mirror of ``qcat.scanner_base.BarcodeScanner``)."""
+
+    #: "epi2me" or "dual": which scan() the native library reproduces
+    _native_mode = None
+
+    def __init__(self, min_quality, kit_name, kit_folder=None,
+                 enable_filter_barcodes=False, scan_middle_adapter=False, device=0):
+        available_kits = adapters.populate_adapter_layouts(kit_folder)
+        self.min_quality = min_quality
+        self.layouts = []
+        self.override_kit_name = None
+        self.enable_filter_barcodes = enable_filter_barcodes
+        self.scan_middle_adapter = scan_middle_adapter
+        self.device = device
+        if kit_name and kit_name.lower() != "auto":
+            wanted = kit_name.lower()
+            self.layouts = [l for l in available_kits if l.kit.lower() == wanted]
+        else:
+            self.layouts = [l for l in available_kits if l.auto_detect]
+        self._kits = {}
+        self._ctx = None
+
+    # -- registry hooks -------------------------------------------------------------------------
+    @staticmethod
+    def get_name():
+        raise NotImplementedError("Abstract class")
+
+    def barcode_count(self):
+        raise NotImplementedError("Abstract class")
+
+    # -- native plumbing ------------------------------------------------------------------------
+    def descriptor(self, layouts=None, qcat_config=None, ends=native.ENDS_BOTH):
+        """KitDescriptor for ``layouts`` (default: this scanner's) -- also used by the tests to
+        drive the CPU oracle with exactly the product's descriptor."""
+        if qcat_config is None:
+            qcat_config = config.qcatConfig()
+        if layouts is None:
+            layouts = self.layouts
+        return native.KitDescriptor(layouts, qcat_config, mode=self._native_mode,
+                                    min_quality=self.min_quality, ends=ends)
+
+    def _native_kit(self, layouts, qcat_config, ends):
+        key = (tuple(id(l) for l in layouts), qcat_config.fingerprint(), ends, self.min_quality)
+        kit = self._kits.get(key)
+        if kit is None:
+            kit = native.NativeKit(self.descriptor(layouts, qcat_config, ends))
+            self._kits[key] = kit
+        return kit
+
+    def _context(self):
+        if self._ctx is None:
+            self._ctx = native.NativeContext(self.device)
+        return self._ctx
+
+    def _record_to_dict(self, rec, layouts):
+        adapter = layouts[rec["adapter_idx"]] if rec["adapter_idx"] >= 0 else None
+        barcode, score = None, 0.0
+        if rec["barcode_idx"] >= 0:
+            owner = layouts[rec["adapter_idx"]]
+            first = owner.get_barcode_set(0)[rec["barcode_idx"]]
+            if rec["barcode2_idx"] >= 0:
+                second = owner.get_barcode_set(1)[rec["barcode2_idx"]]
+                barcode = Barcode("barcode{:02d}/{:02d}".format(first.id, second.id),
+                                  "{}/{}".format(first.id, second.id), None, True)
+            else:
+                barcode = first
+            score = int(rec["raw_score"]) * 100.0 / (1.0 * int(rec["score_den"]))
+        return build_return_dict(barcode, score, adapter, int(rec["adapter_end"]),
+                                 int(rec["exit_status"]), trim5p=int(rec["trim5p"]),
+                                 trim3p=int(rec["trim3p"]))
+
+    def _run(self, read_sequences, layouts, qcat_config, ends=native.ENDS_BOTH):
+        if self.scan_middle_adapter:
+            raise NotImplementedError("scan_middle_adapter (--detect-middle) is not available on "
+                                      "the MI355X path yet (SURVEY.md 8f rank 3)")
+        if not layouts:
+            # the reference indexes an empty template list here (IndexError)
+            raise IndexError("list index out of range")
+        kit = self._native_kit(layouts, qcat_config, ends)
+        bases, offsets = native.pack_reads(read_sequences)
+        recs = self._context().scan(kit, bases, offsets)
+        return [self._record_to_dict(r, layouts) for r in recs]
+
+    # -- reference API ----------------------------------------------------------------------------
+    def scan(self, read_sequence, read_qualities, barcoding_kits, non_barocding_kits,
+             qcat_config=None):
+        """``scan()`` of one window (``qcat/scanner_epi2me.py:33``, ``scanner_dual.py:35``)."""
+        if qcat_config is None:
+            qcat_config = config.qcatConfig()
+        if not isinstance(barcoding_kits, list):
+            barcoding_kits = [barcoding_kits]
+        window = (read_sequence or "")
+        if len(window) > qcat_config.max_align_length:
+            raise NotImplementedError("scan() of a window longer than max_align_length "
+                                      "(scan_middle) is not available on the MI355X path yet")
+        return self._run([window], barcoding_kits, qcat_config, ends=native.ENDS_5P)[0]
+
+    def detect_barcode(self, read_sequence, read_qualities=None, qcat_config=None):
+        if qcat_config is None:
+            qcat_config = config.qcatConfig()
+        kits = self.layouts if not self.override_kit_name else self.get_adapters(self.override_kit_name)
+        return self._run([read_sequence], kits, qcat_config)[0]
+
+    def get_adapters(self, kit_name):
+        return [l for l in self.layouts if kit_name.lower() == l.kit.lower()]
+
+    def get_adapter(self, kit_name):
+        for layout in self.layouts:
+            if kit_name.lower() == layout.kit.lower():
+                return layout
+
+    @staticmethod
+    def update_kit_count(adapter, adapter_counts):
+        key = adapter.kit if adapter else "none"
+        adapter_counts[key] = adapter_counts.get(key, 0) + 1
+
+    @staticmethod
+    def get_most_abundant_kits(adapter_counts):
+        if not adapter_counts:
+            return None
+        return sorted(adapter_counts.items(), key=operator.itemgetter(1), reverse=True)[0][0]
+
+    def detect_kit(self, read_sequences, qcat_config=None):
+        """Per-batch kit vote (``qcat/scanner_base.py:662-678``).  With one kit selected the vote
+        can only return that kit; kit auto needs the native vote kernel."""
+        kits = []
+        for l in self.layouts:
+            if l.kit not in kits:
+                kits.append(l.kit)
+        if not read_sequences or not kits:
+            return None, []
+        if len(kits) == 1:
+            return kits[0], []
+        raise NotImplementedError("kit auto-detection in batch mode is not available on the "
+                                  "MI355X path yet (SURVEY.md 8f rank 1)")
+
+    @staticmethod
+    def update_barcode_count(result, barcode_count):
+        key = result["barcode"].id if result and result["barcode"] else "0"
+        barcode_count[key] = barcode_count.get(key, 0) + 1
+
+    @staticmethod
+    def get_valid(barcode_counts, min_perc=0.20):
+        top = max(list(barcode_counts.values()) + [0])
+        floor = int(top * min_perc)
+        return [bc for bc, count in barcode_counts.items() if count > floor]
+
+    def filter_barcodes(self, barcode_count, results):
+        valid = self.get_valid(barcode_count, 0.05)
+        for i, res in enumerate(results):
+            if res and res["barcode"] and res["barcode"].id not in valid:
+                results[i] = empty_return_dict()
+        return results
+
+    def detect_barcode_batch(self, read_sequences, read_qualities=[None], qcat_config=None):
+        if qcat_config is None:
+            qcat_config = config.qcatConfig()
+        kit_name, _ = self.detect_kit(read_sequences, qcat_config)
+        # zip() in the reference truncates to the shorter list (R7)
+        n = min(len(read_sequences), len(read_qualities))
+        kits = self.layouts if not kit_name else self.get_adapters(kit_name)
+        results = self._run(list(read_sequences[:n]), kits, qcat_config) if n else []
+        barcode_count = {}
+        for res in results:
+            self.update_barcode_count(res, barcode_count)
+        if self.enable_filter_barcodes:
+            results = self.filter_barcodes(barcode_count, results)
+        return results

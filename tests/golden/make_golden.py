@@ -1,0 +1,388 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by running the UNMODIFIED reference Python
+(/root/reference, read-only) in the authoring container.  Dev tool: it cannot run on the
+GPU box (no /root/reference there) and nothing in tests/ calls it.
+
+What is real and what is a stand-in
+-----------------------------------
+The reference imports two third-party packages that are absent from this image:
+``parasail`` (all DP arithmetic) and ``Bio`` (FASTA/FASTQ parsing).  This script puts two
+minimal stand-in modules on ``sys.path`` (written to a temp dir, never committed as part of
+the product):
+  * ``parasail``: ``matrix_create`` (mutable ``pointer[0].matrix`` as qcat/config.py:247-253
+    needs), ``sg_striped_32``/``sg`` forwarding to the oracle DP ``qo_sg`` (oracle/qcat_oracle.c),
+    ``can_use_sse2``.
+  * ``Bio.SeqIO.FastaIO.SimpleFastaParser`` / ``Bio.SeqIO.QualityIO.FastqGeneralIterator``.
+Consequence: the fixtures pin everything ABOVE the parasail call -- windowing, template
+arg-max, region slicing, the barcode arg-max quirk, thresholds, trims, conflict handling,
+dual combination, batch/kit vote -- against the reference's own code.  The DP below the call
+is the oracle's restatement in both the fixture and the test, so the fixtures do NOT pin the
+DP; that is pinned only by the reference's known answers (tests/test_oracle_reference_vectors.py).
+
+Template order: ``glob.glob`` is wrapped with ``sorted`` before qcat is imported, i.e. the
+sorted-by-file-name order this build fixes.
+
+Outputs (tests/golden/):
+  inline_reads.json      the inline read strings held by qcat/test/test_barcode.py (data)
+  data/*.fastq           the four FASTQ files of qcat/test/data (data)
+  golden_vectors.json    reference outputs for the cases below
+"""
+import glob
+import json
+import os
+import shutil
+import sys
+import tempfile
+import textwrap
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_lib  # noqa: E402
+import synth  # noqa: E402
+import numpy as np  # noqa: E402
+
+
+def install_standins():
+    d = tempfile.mkdtemp(prefix="qcat_standins_")
+    os.makedirs(os.path.join(d, "Bio", "SeqIO"))
+    open(os.path.join(d, "Bio", "__init__.py"), "w").close()
+    open(os.path.join(d, "Bio", "SeqIO", "__init__.py"), "w").close()
+    with open(os.path.join(d, "Bio", "SeqIO", "FastaIO.py"), "w") as fh:
+        fh.write(textwrap.dedent('''
+            def SimpleFastaParser(handle):
+                title, seq = None, []
+                for line in handle:
+                    line = line.rstrip("\\n")
+                    if line.startswith(">"):
+                        if title is not None:
+                            yield title, "".join(seq)
+                        title, seq = line[1:], []
+                    elif title is not None:
+                        seq.append(line.strip())
+                if title is not None:
+                    yield title, "".join(seq)
+            '''))
+    with open(os.path.join(d, "Bio", "SeqIO", "QualityIO.py"), "w") as fh:
+        fh.write(textwrap.dedent('''
+            def FastqGeneralIterator(handle):
+                while True:
+                    head = handle.readline()
+                    if not head:
+                        return
+                    seq = handle.readline().rstrip("\\n")
+                    handle.readline()
+                    qual = handle.readline().rstrip("\\n")
+                    yield head.rstrip("\\n")[1:], seq, qual
+            '''))
+    with open(os.path.join(d, "parasail.py"), "w") as fh:
+        fh.write(textwrap.dedent('''
+            """Stand-in for parasail backed by the oracle DP (see tests/golden/make_golden.py)."""
+            import numpy as np
+            import oracle_lib
+
+            CALLS = {"n": 0, "cells": 0}
+
+            class _Inner(object):
+                def __init__(self, flat):
+                    self.matrix = flat
+
+            class Matrix(object):
+                def __init__(self, alphabet, match, mismatch):
+                    n = len(alphabet)
+                    self.alphabet = alphabet
+                    self.size = n + 1
+                    flat = []
+                    for i in range(n):
+                        flat += [match if i == j else mismatch for j in range(n)] + [0]
+                    flat += [0] * (n + 1)
+                    self.pointer = [_Inner(flat)]
+
+                def table7(self):
+                    """-> 7x7 int8 [target, query] over A T G C N X other."""
+                    full = "ATGCNX"
+                    idx = [self.alphabet.index(c) if c in self.alphabet else self.size - 1 for c in full]
+                    idx.append(self.size - 1)
+                    m = np.array(self.pointer[0].matrix, dtype=np.int64).reshape(self.size, self.size)
+                    return m[np.ix_(idx, idx)].astype(np.int8)
+
+            class Result(object):
+                def __init__(self, score, end_query, end_ref):
+                    self.score, self.end_query, self.end_ref = score, end_query, end_ref
+
+            def can_use_sse2():
+                return True
+
+            def matrix_create(alphabet, match, mismatch):
+                return Matrix(alphabet, match, mismatch)
+
+            def sg_striped_32(s1, s2, open, extend, matrix):
+                CALLS["n"] += 1
+                CALLS["cells"] += len(s1) * len(s2)
+                return Result(*oracle_lib.sg(s1, s2, open, extend, matrix.table7()))
+
+            sg = sg_striped_32
+
+            def sg_stats_striped_32(*a, **k):
+                raise NotImplementedError("stats alignments are outside the hot path")
+
+            sg_stats = sg_stats_striped_32
+            '''))
+    sys.path.insert(0, d)
+    return d
+
+
+def import_reference():
+    _glob = glob.glob
+    glob.glob = lambda *a, **k: sorted(_glob(*a, **k))        # R8: sorted template order
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    import qcat.scanner as ref_scanner                        # noqa
+    import qcat.scanner_base as ref_base                      # noqa
+    import qcat.scanner_epi2me as ref_epi                     # noqa
+    import qcat.scanner_dual as ref_dual                      # noqa
+    import qcat.config as ref_config                          # noqa
+    return ref_scanner, ref_base, ref_epi, ref_dual, ref_config
+
+
+class Tracer(object):
+    """Records the intermediates of every scan() by wrapping the helper functions in the
+    namespaces of the two scanner modules (they import the helpers by name)."""
+
+    def __init__(self, mods):
+        self.ends = []
+        self.cur = None
+        for mod in mods:
+            self._wrap(mod)
+
+    def _wrap(self, mod):
+        fbt, ebr, fhs = mod.find_best_adapter_template, mod.extract_barcode_region, mod.find_highest_scoring_barcode
+        tracer = self
+        import parasail
+
+        def find_best(adapter_templates, read_sequence, qcat_config):
+            tracer.cur = {"window_len": len(read_sequence or ""), "tpl_raw": [], "tpl_end": [],
+                          "regions": [], "rows": [], "winners": []}
+            tracer.ends.append(tracer.cur)
+            # per-template raw scores through the reference's own eval_adapter_template
+            import qcat.scanner_base as sb
+            if adapter_templates and read_sequence:
+                for tpl in adapter_templates:
+                    end, _, raw = sb.eval_adapter_template(tpl, read_sequence, qcat_config, identity=False)
+                    tracer.cur["tpl_raw"].append(raw)
+                    tracer.cur["tpl_end"].append(end)
+            ret = fbt(adapter_templates=adapter_templates, read_sequence=read_sequence, qcat_config=qcat_config)
+            tracer.cur["best"] = [ret[0], ret[1], float(ret[2]).hex()]
+            return ret
+
+        def region(read_sequence, adapter_template, barcode_set_index, alignment_stop_ref, qcat_config):
+            out = ebr(read_sequence=read_sequence, adapter_template=adapter_template,
+                      barcode_set_index=barcode_set_index, alignment_stop_ref=alignment_stop_ref,
+                      qcat_config=qcat_config)
+            tracer.cur["regions"].append([barcode_set_index, out])
+            return out
+
+        def highest(barcode_region_read, barcode_set, qcat_config, upstream_context="", downstream_context="",
+                    compute_identity=False):
+            row = []
+            if barcode_region_read:
+                for bc in barcode_set:
+                    r = parasail.sg_striped_32(barcode_region_read, upstream_context + bc.sequence + downstream_context,
+                                               1, 1, qcat_config.matrix_barcode)
+                    row.append(r.score)
+            ret = fhs(barcode_region_read=barcode_region_read, barcode_set=barcode_set, qcat_config=qcat_config,
+                      upstream_context=upstream_context, downstream_context=downstream_context)
+            tracer.cur["rows"].append(row)
+            tracer.cur["winners"].append([barcode_set.index(ret[0]) if ret[0] is not None else -1,
+                                          len(barcode_region_read or ""),
+                                          len(upstream_context) + len(downstream_context)])
+            return ret
+
+        mod.find_best_adapter_template = find_best
+        mod.extract_barcode_region = region
+        mod.find_highest_scoring_barcode = highest
+
+    def take(self):
+        ends, self.ends = self.ends, []
+        return ends
+
+
+def result_to_json(res, layouts):
+    bc = res["barcode"]
+    ad = res["adapter"]
+    return {"barcode_id": None if bc is None else bc.id,
+            "barcode_name": None if bc is None else bc.name,
+            "score_hex": float(res["barcode_score"]).hex(),
+            "adapter_kit": None if ad is None else ad.kit,
+            "adapter_idx": -1 if ad is None else [id(l) for l in layouts].index(id(ad)),
+            "adapter_end": res["adapter_end"], "trim5p": res["trim5p"], "trim3p": res["trim3p"],
+            "exit_status": res["exit_status"]}
+
+
+def end_to_json(e, keep_rows):
+    out = {"window_len": e["window_len"], "tpl_raw": e["tpl_raw"], "tpl_end": e["tpl_end"],
+           "best": e["best"], "regions": [[s, len(r)] for s, r in e["regions"]],
+           "region_text": [r for _, r in e["regions"]] if keep_rows else None,
+           "winners": e["winners"]}
+    if keep_rows:
+        out["rows"] = e["rows"]
+    return out
+
+
+def main():
+    install_standins()
+    ref_scanner, ref_base, ref_epi, ref_dual, ref_config = import_reference()
+    import parasail
+    tracer = Tracer([ref_epi, ref_dual])
+    cfg = ref_config.qcatConfig()
+
+    # ---- data held by the reference's tests -------------------------------------------------
+    import qcat.test.test_barcode as ref_tests
+    inline_names = ["read", "read_bc3_exact", "read_bc3", "real_bc03_porechop", "read_nobc",
+                    "real_double_barcode_read"]
+    inline = {n: getattr(ref_tests, n) for n in inline_names if hasattr(ref_tests, n)}
+    with open(os.path.join(HERE, "inline_reads.json"), "w") as fh:
+        json.dump({"source": "qcat/test/test_barcode.py:71-288 (module-level read strings)", "reads": inline},
+                  fh, indent=0)
+    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
+    fastq = {}
+    for path in sorted(glob.glob(os.path.join(REF, "qcat", "test", "data", "*.fastq"))):
+        shutil.copyfile(path, os.path.join(HERE, "data", os.path.basename(path)))
+        with open(path) as fh:
+            lines = fh.read().split("\n")
+        fastq[os.path.basename(path)] = [(lines[i][1:], lines[i + 1]) for i in range(0, len(lines) - 3, 4)]
+
+    cases = []
+
+    def run_case(name, mode, kit, reads, keep_rows=False, min_quality=None, note=None, gen=None):
+        det = ref_scanner.factory(mode=mode, kit=kit, min_quality=min_quality)
+        layouts = det.layouts
+        recs = []
+        n_align0, cells0 = parasail.CALLS["n"], parasail.CALLS["cells"]
+        for r in reads:
+            tracer.take()
+            res = det.detect_barcode(r, qcat_config=cfg)
+            ends = tracer.take()
+            recs.append({"result": result_to_json(res, layouts),
+                         "ends": [end_to_json(e, keep_rows) for e in ends]})
+        case = {"name": name, "mode": mode, "kit": kit, "min_quality": det.min_quality,
+                "layout_kits": [l.kit for l in layouts],
+                "layout_lens": [l.get_adapter_length() for l in layouts],
+                "records": recs, "note": note}
+        if gen is not None:
+            case["gen"] = gen                # reads are re-generated from seeds by the tests
+        else:
+            case["reads"] = reads
+        cases.append(case)
+        print("%-34s %4d reads  %7d alignments (incl. trace re-runs)" % (name, len(reads), parasail.CALLS["n"] - n_align0))
+
+    # 1. the 34 shipped reads, kit auto and the file's own kit
+    file_kits = {"nbd103.fastq": "NBD104/NBD114", "pbk004.fastq": "PBK004/LWB001",
+                 "rab204.fastq": "RAB204/RAB214", "rbk004.fastq": "RBK004"}
+    for fname, recs in fastq.items():
+        run_case("fastq:%s:auto" % fname, "epi2me", None, [s for _, s in recs], note=[h for h, _ in recs])
+        run_case("fastq:%s:kit" % fname, "epi2me", file_kits[fname], [s for _, s in recs], keep_rows=(fname == "nbd103.fastq"))
+
+    # 2. inline reads of the reference tests
+    inl = [inline[n] for n in inline_names] + [""]
+    run_case("inline:auto", "epi2me", None, inl)
+    run_case("inline:RBK001", "epi2me", "RBK001", inl, keep_rows=True)
+    run_case("inline:dual", "dual", None, inl, keep_rows=True)
+
+    # 3. edge cases under PBC096
+    pbc5 = [l for l in ref_scanner.get_adapter_by_name("PBC096") if l.get_adapter_length() == 59][0]
+    exact = synth.fill(pbc5, 0, 0)
+    body = synth.synth_read(7, 99, [pbc5], -1, -1, insert_len=400)
+    edge = ["", "A", body[:32], "N" * 200, ("ACGTTGCA" + exact + body).lower(),
+            body[:1], body[:30], body[:149], body[:150], body[:151], body[:299], body[:300],
+            "ACGT" + exact[:30] + "NNNN" + exact[34:] + body, "RYKM" + exact + "U" * 10 + body[:200] + "*-",
+            exact, exact[:40], exact[20:] + body[:100], body[:100] + synth.revcomp_acgt(exact),
+            "G" * 7 + exact + body[:300] + synth.revcomp_acgt(synth.fill(pbc5, 5, 0)) + "C" * 9]
+    run_case("edge:PBC096", "epi2me", "PBC096", edge, keep_rows=True)
+    run_case("edge:auto", "epi2me", None, edge)
+    run_case("edge:dual", "dual", None, edge)
+
+    # 4. synthetic reads (re-generated by the tests from the stored parameters)
+    def synth_case(tag, mode, kit, t5, t3, e, n, seed, keep_rows=False):
+        det = ref_scanner.factory(mode=mode, kit=kit)
+        gen = {"seed": seed, "n": n, "tpl_5p": t5, "tpl_3p": t3, "error_rate": e,
+               "no_adapter_fraction": 0.05, "insert_len": 600, "lead_min": 5, "lead_max": 40}
+        reads = synth.synth_batch(n, seed, det.layouts, t5, t3, error_rate=e)
+        run_case("synth:%s:e%.2f" % (tag, e), mode, kit, reads, keep_rows=keep_rows, gen=gen)
+
+    seed0 = 20260928
+    for e in (0.0, 0.08, 0.15):
+        # sorted order puts the 3p template first (index 0) and the 5p template second
+        synth_case("LWB001", "epi2me", "PBK004/LWB001", 1, 0, e, 48, seed0 + 1, keep_rows=(e == 0.08))
+        synth_case("NBD104", "epi2me", "NBD103/NBD104", 1, 0, e, 48, seed0 + 2)
+        synth_case("PBC096", "epi2me", "PBC096", 1, 0, e, 48, seed0 + 3, keep_rows=(e == 0.08))
+        synth_case("DUAL", "dual", None, 1, 0, e, 48, seed0 + 5, keep_rows=(e == 0.08))
+        synth_case("DUAL-epi2me", "epi2me", "DUAL", 1, 0, e, 16, seed0 + 6)
+        synth_case("auto", "epi2me", None, 3, 2, e, 32, seed0 + 7)     # PBC096 reads under kit auto
+    synth_case("RBK004", "epi2me", "RBK004", 0, -1, 0.08, 32, seed0 + 8)
+    synth_case("VMK001", "epi2me", "VMK001", 0, -1, 0.08, 32, seed0 + 9)
+    synth_case("RAB204", "epi2me", "RAB204", 1, 0, 0.08, 32, seed0 + 10)
+    synth_case("RPB004", "epi2me", "RPB004/RLB001", 0, -1, 0.08, 32, seed0 + 11)
+
+    # 5. extract_barcode_region slice table (negative-index wrap, R4)
+    region_table = []
+    window = body[:150]
+    for kit, tidx in (("PBC096", 1), ("NBD103/NBD104", 0), ("DUAL", 1)):
+        tpl = [l for l in ref_scanner.factory(mode="epi2me", kit=kit).layouts][tidx]
+        for L in (150, 64, 20):
+            for setidx in ((0, 1) if tpl.barcode_set_2 else (0,)):
+                rows = []
+                for stop in range(-1, L):
+                    out = ref_base.extract_barcode_region(window[:L], tpl, setidx, stop, cfg)
+                    start = window[:L].find(out) if out else 0
+                    rows.append(len(out))
+                region_table.append({"kit": kit, "tpl": tidx, "set": setidx, "L": L, "lens": rows})
+
+    # 6. batch mode (detect_kit vote + detect_barcode_batch), SURVEY 8f rank 1
+    batch = []
+    five = [inline[n] for n in ("read", "read_bc3_exact", "read_bc3", "real_bc03_porechop", "read_nobc")]
+    for kit in (None, "RBK001"):
+        det = ref_scanner.factory(mode="epi2me", kit=kit)
+        kit_name, _ = det.detect_kit(five, cfg)
+        res = det.detect_barcode_batch(five, [None] * 5, cfg)
+        batch.append({"kit": kit, "voted_kit": kit_name,
+                      "results": [result_to_json(r, det.layouts) for r in res]})
+    allfq = [s for recs in fastq.values() for _, s in recs]
+    det = ref_scanner.factory(mode="epi2me", kit=None)
+    per_file_votes = {}
+    for fname, recs in fastq.items():
+        kit_name, _ = det.detect_kit([s for _, s in recs], cfg)
+        res = det.detect_barcode_batch([s for _, s in recs], [None] * len(recs), cfg)
+        per_file_votes[fname] = {"voted_kit": kit_name,
+                                 "results": [result_to_json(r, det.layouts) for r in res]}
+
+    # 7. scan() of the 5' window only (BASELINE config 2 semantics)
+    det = ref_scanner.factory(mode="epi2me", kit="NBD103/NBD104")
+    reads5 = synth.synth_batch(48, seed0 + 12, det.layouts, 1, 0, error_rate=0.08)
+    scan5 = []
+    for r in reads5:
+        w = ref_base.extract_align_sequence(r, False, cfg.max_align_length)
+        tracer.take()
+        res = det.scan(w, None, det.layouts, [], qcat_config=cfg)
+        tracer.take()
+        scan5.append(result_to_json(res, det.layouts))
+
+    with open(os.path.join(HERE, "golden_vectors.json"), "w") as fh:
+        json.dump({"generator": "tests/golden/make_golden.py",
+                   "template_order": "sorted by kit file name",
+                   "dp": "oracle restatement (parasail absent) -- see make_golden.py docstring",
+                   "cases": cases, "region_table": region_table, "batch": batch,
+                   "batch_fastq": per_file_votes,
+                   "scan5p": {"kit": "NBD103/NBD104",
+                              "gen": {"seed": seed0 + 12, "n": 48, "tpl_5p": 1, "tpl_3p": 0, "error_rate": 0.08,
+                                      "no_adapter_fraction": 0.05, "insert_len": 600, "lead_min": 5, "lead_max": 40},
+                              "results": scan5}},
+                  fh, separators=(",", ":"))
+    print("golden_vectors.json:", os.path.getsize(os.path.join(HERE, "golden_vectors.json")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

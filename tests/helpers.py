@@ -1,0 +1,104 @@
+"""Shared helpers of the test-suite: golden fixtures, scanner/descriptor construction and the
+record comparison used for BOTH the oracle-vs-reference tests (CPU) and the HIP-vs-oracle /
+HIP-vs-golden tests (GPU)."""
+import json
+import os
+
+import numpy as np
+
+import synth
+from qcat_amd import config, native, scanner
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+_cache = {}
+
+
+def golden():
+    if "g" not in _cache:
+        with open(os.path.join(GOLDEN, "golden_vectors.json")) as fh:
+            _cache["g"] = json.load(fh)
+    return _cache["g"]
+
+
+def inline_reads():
+    with open(os.path.join(GOLDEN, "inline_reads.json")) as fh:
+        return json.load(fh)["reads"]
+
+
+def fastq_records(name):
+    with open(os.path.join(GOLDEN, "data", name)) as fh:
+        lines = fh.read().split("\n")
+    return [(lines[i][1:], lines[i + 1]) for i in range(0, len(lines) - 3, 4)]
+
+
+def make_scanner(mode, kit, min_quality=None):
+    return scanner.factory(mode=mode, kit=kit, min_quality=min_quality)
+
+
+def case_reads(case, layouts):
+    if "reads" in case:
+        return case["reads"]
+    g = case["gen"]
+    return synth.synth_batch(g["n"], g["seed"], layouts, g["tpl_5p"], g["tpl_3p"],
+                             error_rate=g["error_rate"], no_adapter_fraction=g["no_adapter_fraction"],
+                             insert_len=g["insert_len"], lead_min=g["lead_min"], lead_max=g["lead_max"])
+
+
+def record_as_golden(rec, layouts, mode):
+    """native/oracle record -> the JSON shape make_golden.py stores for a reference dict."""
+    out = {"barcode_id": None, "barcode_name": None, "adapter_kit": None,
+           "adapter_idx": int(rec["adapter_idx"]), "adapter_end": int(rec["adapter_end"]),
+           "trim5p": int(rec["trim5p"]), "trim3p": int(rec["trim3p"]),
+           "exit_status": int(rec["exit_status"])}
+    score = 0.0
+    if rec["adapter_idx"] >= 0:
+        out["adapter_kit"] = layouts[rec["adapter_idx"]].kit
+    if rec["barcode_idx"] >= 0:
+        lay = layouts[rec["adapter_idx"]]
+        b1 = lay.get_barcode_set(0)[rec["barcode_idx"]]
+        if mode == "dual":
+            b2 = lay.get_barcode_set(1)[rec["barcode2_idx"]]
+            out["barcode_id"] = "{}/{}".format(b1.id, b2.id)
+            out["barcode_name"] = "barcode{:02d}/{:02d}".format(b1.id, b2.id)
+        else:
+            out["barcode_id"], out["barcode_name"] = b1.id, b1.name
+        score = int(rec["raw_score"]) * 100.0 / (1.0 * int(rec["score_den"]))
+    out["score_hex"] = float(score).hex()
+    return out
+
+
+def assert_case_matches(case, recs, traces, rows, layouts):
+    """Compare records (+ optional traces / per-barcode rows) with one golden case."""
+    mode = case["mode"]
+    assert [l.kit for l in layouts] == case["layout_kits"]
+    assert [l.get_adapter_length() for l in layouts] == case["layout_lens"]
+    assert len(recs) == len(case["records"])
+    for i, want in enumerate(case["records"]):
+        got = record_as_golden(recs[i], layouts, mode)
+        assert got == want["result"], "%s read %d: %r != %r" % (case["name"], i, got, want["result"])
+        if traces is None:
+            continue
+        for e, wend in enumerate(want["ends"]):
+            tr = traces[2 * i + e]
+            nt = len(layouts)
+            assert tr["window_len"] == wend["window_len"]
+            if wend["tpl_raw"]:
+                assert list(tr["tpl_raw"][:nt]) == wend["tpl_raw"], (case["name"], i, e)
+                assert list(tr["tpl_end"][:nt]) == wend["tpl_end"], (case["name"], i, e)
+            assert [int(tr["best_tpl"]), int(tr["best_end"])] == wend["best"][:2], (case["name"], i, e)
+            # regions: the reference calls extract_barcode_region only on the region path
+            sets_with_region = {s: n for s, n in wend["regions"]}
+            for k, (widx, rlen, _ctx) in enumerate(wend["winners"]):
+                if mode != "dual" and k == 1:
+                    continue          # epi2me's discarded second scan (scanner_epi2me.py:104-131)
+                assert int(tr["region_len"][k]) == rlen, (case["name"], i, e, k)
+                assert int(tr["bc_idx"][k]) == widx, (case["name"], i, e, k)
+                if k in sets_with_region:
+                    assert sets_with_region[k] == rlen
+            assert bool(tr["region_path"]) == (0 in sets_with_region)
+            if rows is not None and wend.get("rows") is not None:
+                for k, wrow in enumerate(wend["rows"]):
+                    if mode != "dual" and k == 1:
+                        continue
+                    assert list(rows[2 * i + e, k, :len(wrow)]) == wrow, (case["name"], i, e, k)

