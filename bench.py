@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the barcode-demultiplexing hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (pack windows -> adapter scan -> barcode scan -> finalize ->
+count histogram, + one RCCL all-reduce of the count vector when N > 1) over one batch of
+synthetic reads that is already resident in HBM.  Default workload = BASELINE.json configs[1]:
+1 M synthetic reads per GPU, 12-barcode NBD103/NBD104 kit, 5' end only.  Weak scaling: every rank
+owns its own 1 M-read shard (distinct seed), so value = N * reads_per_gpu * steps / time.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel's ALGORITHMIC bytes
+(150 B per scanned read end + 24 B result record) against the 8 TB/s HBM peak,
+with the kernel's average duration measured by HIP events on the library's own stream;
+`cpu_baseline` times the CPU oracle (a port, not the reference: parasail is absent) on a bounded
+sample of the same reads on the host cores of this box.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+from qcat_amd import config as qconfig  # noqa: E402
+from qcat_amd import native, scanner  # noqa: E402
+
+WORKLOADS = {
+    # name: (mode, kit, ends, tpl_5p, tpl_3p, algorithmic bytes per read)
+    "config2": ("epi2me", "NBD103/NBD104", native.ENDS_5P, 1, 0, 174),
+    "config3": ("epi2me", "PBC096", native.ENDS_BOTH, 1, 0, 324),
+    "dual": ("dual", None, native.ENDS_BOTH, 1, 0, 324),
+}
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=1000000, help="reads per GPU per step")
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS))
+    ap.add_argument("--error-rate", type=float, default=0.08)
+    ap.add_argument("--seed", type=int, default=20260928 + 1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if a.gpus != world:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+
+    mode, kit_name, ends, t5, t3, bytes_per_read = WORKLOADS[a.workload]
+    det = scanner.factory(mode=mode, kit=kit_name, device=local_rank)
+    cfg = qconfig.qcatConfig()
+    desc = det.descriptor(qcat_config=cfg, ends=ends)
+    hip = native.HipLibrary.get()
+    lib = hip.lib
+    kit = native.NativeKit(desc)
+    ctx = native.NativeContext(local_rank)
+    n_buckets = desc.n_count_buckets
+
+    sp = native.SynthParams(seed=a.seed + 1000003 * rank, n_reads=a.reads, insert_len=600, lead_min=5,
+                            lead_max=40, error_rate=a.error_rate, no_adapter_fraction=0.05,
+                            tpl_5p=t5, tpl_3p=t3)
+    batch = C.c_void_p()
+    hip.check(lib.qcat_batch_synthesize(ctx.handle, kit.handle, C.byref(sp), C.byref(batch)))
+    nb = C.c_uint64()
+    nr = C.c_uint32()
+    hip.check(lib.qcat_batch_info(batch, C.byref(nr), C.byref(nb)))
+
+    counts_t = None
+    if world > 1:
+        counts_t = torch.zeros(n_buckets, dtype=torch.int64, device="cuda")
+        host_counts = np.zeros(n_buckets, dtype=np.int64)
+
+    def step(reduce_counts=True):
+        hip.check(lib.qcat_scan_resident(ctx.handle, kit.handle, batch))
+        if world > 1 and reduce_counts:
+            # per-barcode / per-kit count vector: the only cross-GPU exchange of the path
+            hip.check(lib.qcat_ctx_fetch_counts(ctx.handle, host_counts.ctypes.data, n_buckets))
+            counts_t.copy_(torch.from_numpy(host_counts))
+            dist.all_reduce(counts_t, op=dist.ReduceOp.SUM)
+
+    def sync_all():
+        hip.check(lib.qcat_ctx_synchronize(ctx.handle))
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    hip.check(lib.qcat_ctx_set_timing(ctx.handle, 1))
+    kernel_ms = {}
+    names = (C.c_char_p * 16)()
+    ms = (C.c_float * 16)()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+        k = lib.qcat_ctx_last_timing(ctx.handle, names, ms, 16)     # synchronises the stream
+        for i in range(k):
+            kernel_ms.setdefault(names[i].decode(), []).append(float(ms[i]))
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- results of the last step: parity spot check + counts -------------------------------
+    recs = np.zeros(a.reads, dtype=native.RESULT_DTYPE)
+    hip.check(lib.qcat_ctx_fetch_results(ctx.handle, recs.ctypes.data, a.reads))
+    cnt = np.zeros(n_buckets, dtype=np.int64)
+    hip.check(lib.qcat_ctx_fetch_counts(ctx.handle, cnt.ctypes.data, n_buckets))
+    total_counts = cnt.copy()
+    if world > 1:
+        total_counts = counts_t.cpu().numpy()
+
+    out = None
+    if rank == 0:
+        value = world * a.reads * a.steps / elapsed
+        avg = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
+        dom = max(avg, key=avg.get) if avg else None
+        roof = None
+        if dom:
+            achieved = a.reads * bytes_per_read / (avg[dom] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "algorithmic_bytes_per_launch": a.reads * bytes_per_read,
+                    "avg_launch_ms": round(avg[dom], 4),
+                    "kernels_avg_ms": {k: round(v, 4) for k, v in avg.items()},
+                    "note": "integer DP: VALU-issue bound, not HBM bound (SURVEY.md 8d); see valu"}
+        out = {"metric": "reads/sec demultiplexed", "value": round(value, 1), "unit": "reads/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+               "config": {"workload": "%s: %d synthetic reads/GPU, kit %s (%s), %s, error rate %.2f, "
+                                      "~%d nt reads" % (a.workload, a.reads, kit_name or "DUAL", mode,
+                                                        "5' end only" if ends == native.ENDS_5P else "5'+3' ends with trims",
+                                                        a.error_rate, nb.value // max(1, a.reads)),
+                          "reads_per_gpu": a.reads, "kit": kit_name or "DUAL", "mode": mode,
+                          "n_barcodes": len(det.layouts[0].barcode_set_1), "parallelism": "reads sharded x%d" % world},
+               "roofline": roof,
+               "counts_total": int(total_counts[: n_buckets - len(desc.kit_names) - 1].sum())}
+
+        # ---- CPU baseline + parity on a bounded sample of rank 0's shard ---------------------
+        if not a.no_cpu_baseline:
+            import oracle_lib
+            ncpu = os.cpu_count() or 1
+
+            def sample_reads(n):
+                buf = np.zeros(4096, dtype=np.uint8)
+                chunks, offs = [], np.zeros(n + 1, dtype=np.uint64)
+                for i in range(n):
+                    ln = lib.qcat_synth_read(kit.handle, C.byref(sp), i, buf.ctypes.data, buf.size)
+                    chunks.append(buf[:ln].tobytes())
+                    offs[i + 1] = offs[i] + ln
+                return np.frombuffer(b"".join(chunks), dtype=np.uint8), offs
+
+            probe = min(2000, a.reads)
+            packed = sample_reads(probe)
+            t1 = time.perf_counter()
+            o1, tr1 = oracle_lib.scan(desc, packed=packed, trace=True, threads=1)
+            one_thread = probe / (time.perf_counter() - t1)
+            n_sample = int(min(a.reads, max(probe, one_thread * ncpu * a.cpu_seconds * 0.6)))
+            n_sample = min(n_sample, 400000)
+            packed = sample_reads(n_sample)
+            t1 = time.perf_counter()
+            o = oracle_lib.scan(desc, packed=packed, threads=ncpu)
+            all_cores = n_sample / (time.perf_counter() - t1)
+            mism = int(np.count_nonzero(o != recs[:n_sample]))
+            # reference-defined DP cells per read on the probe (second figure)
+            lays = det.layouts
+            cells = 0
+            n_end = 1 if ends == native.ENDS_5P else 2
+            tl = sum(l.get_adapter_length() for l in lays)
+            for t in tr1:
+                cells += int(t["window_len"]) * tl
+                lay = lays[int(t["used_tpl"])]
+                for s in range(2 if mode == "dual" else 1):
+                    bs = lay.get_barcode_set(s)
+                    tlen = (len(lay.get_upstream_context(cfg.barcode_context_length, s)) + len(bs[0].sequence)
+                            + len(lay.get_downstream_context(cfg.barcode_context_length, s)))
+                    cells += len(bs) * int(t["region_len"][s]) * tlen
+            cells_per_read = cells / float(probe)
+            out["cpu_baseline"] = {"value": round(all_cores, 1), "unit": "reads/s", "cores": ncpu, "kind": "port",
+                                   "sample": "first %d reads of rank 0's shard, oracle/qcat_oracle.c with OpenMP over "
+                                             "%d threads (1 thread: %.0f reads/s on %d reads)" % (n_sample, ncpu, one_thread, probe)}
+            out["parity"] = {"checked_reads": n_sample, "mismatches_vs_oracle": mism}
+            out["valu"] = {"dp_cells_per_read": round(cells_per_read, 1),
+                           "cell_updates_per_s": round(value * cells_per_read, 1),
+                           "peak_u16x2_cells_per_s": 256 * 4 * 32 * 2.4e9 * 2 / 4,
+                           "note": "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz x 2 cells / 4 VALU ops per packed cell pair"}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    lib.qcat_batch_destroy(batch)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

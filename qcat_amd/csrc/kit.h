@@ -1,0 +1,95 @@
+// kit.h -- prepared kit: what the kernels read.  Built on the host from a qcat_kit_desc
+// (include/qcat_hip.h) by kit_prepare() and copied verbatim to device memory.
+//
+// Every float decision of the reference is turned into an integer threshold HERE, on the host,
+// with the same IEEE double expression the reference evaluates (Python float == C double):
+//   * get_norm_socre            score*100.0/den            (qcat/scanner_base.py:299-310)
+//   * barcode score             raw*100.0/(1.0*len(target)) (qcat/scanner_base.py:119)
+//   * `> 90.0`, `< min_quality`, `>= 60`                    (scanner_epi2me.py:74, scanner_base.py:546-548,:585-588)
+// Both maps are monotone in the integer raw score (den > 0 is required), so "smallest raw that
+// passes" is an exact replacement; comparisons BETWEEN two normalised scores are done by integer
+// cross-multiplication (distinct rationals with these magnitudes never round to one double).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/qcat_hip.h"
+
+namespace qk {
+
+constexpr int MAX_T = QCAT_MAX_TEMPLATES;
+constexpr int MAX_TLEN = QCAT_MAX_TEMPLATE_LEN;
+constexpr int MAX_TARGET = QCAT_MAX_TARGET_LEN;
+constexpr int MAX_WIN = QCAT_MAX_WINDOW;
+constexpr int WIN_STRIDE = 160;          // bytes per packed code window (16-B aligned rows)
+constexpr int RAW_NEVER = 1 << 20;       // "no raw score passes"
+
+struct DevSet {
+    int32_t n, blen, tlen, uplen, downlen;
+    int32_t tgt_off;            // codes blob: n * tlen target codes (up + barcode + down)
+    int32_t ids_off;            // ids blob: n dense ids
+    int32_t tbl_off;            // tables blob: n * tlen dwords (fast path), -1 if not eligible
+    int32_t min_raw_pass;       // smallest raw with raw*100.0/tlen >= min_quality
+    int32_t min_raw_conflict;   // smallest raw with raw*100.0/tlen >= conflict_min_score
+};
+
+struct DevTpl {
+    int32_t len, trim_offset, is_double, den, kit_slot;
+    int32_t bc_end[2], bc_len[2];
+    int32_t region_min_raw;     // smallest raw with raw*100.0/den > region_min_adapter_score
+    int32_t code_off;           // codes blob: len template codes
+    int32_t tbl_off;            // tables blob: len dwords (fast path), -1 if not eligible
+    DevSet sets[2];
+};
+
+struct DevKit {
+    int32_t mode, ends, nt;
+    int32_t gap_open, gap_extend, max_align, ext;
+    int32_t n_barcode_slots, n_kit_slots, n_buckets;
+    int32_t fast_ok;            // every template/set is eligible for the packed fast path
+    uint32_t special_adapter;   // v_perm pool bytes for query codes N, X, other, PAD (adapter)
+    uint32_t special_barcode;   //   "    (barcode alignments)
+    int8_t amat[49], bmat[49];
+    int8_t pad_[2];
+    DevTpl tpl[MAX_T];
+};
+
+// compact per-read-end record produced by the scan kernels and consumed by k_finalize
+struct EndRec {
+    int32_t window_len;
+    int32_t best_tpl;           // -1: no template beat -1.0
+    int32_t used_tpl;           // Python [-1] wrap applied
+    int32_t best_end, best_raw;
+    int32_t region_path;
+    int32_t region_start[2], region_len[2];
+    int32_t bc_idx[2], bc_raw[2];
+};
+
+struct HostKit {
+    DevKit dk;
+    std::vector<uint8_t> codes;
+    std::vector<int32_t> ids;
+    std::vector<uint32_t> tables;
+    // ASCII copies for the synthetic generator (host + device)
+    std::vector<char> ascii;                 // templates then barcode blobs
+    int32_t ascii_tpl_off[MAX_T];
+    int32_t ascii_set_off[MAX_T][2];
+    int32_t bc_start[MAX_T][2];
+};
+
+int kit_prepare(const qcat_kit_desc* d, HostKit* out, std::string* err);
+
+inline uint8_t code_of_ascii(uint8_t c) {
+    switch (c & 0xDF) {
+        case 'A': return QCAT_CODE_A;
+        case 'T': return QCAT_CODE_T;
+        case 'G': return QCAT_CODE_G;
+        case 'C': return QCAT_CODE_C;
+        case 'N': return QCAT_CODE_N;
+        case 'X': return QCAT_CODE_X;
+        default: return QCAT_CODE_OTHER;
+    }
+}
+
+}  // namespace qk

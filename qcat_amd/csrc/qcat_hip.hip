@@ -1,0 +1,538 @@
+// qcat_hip.hip -- libqcat_hip.so: C ABI (include/qcat_hip.h) + host orchestration.
+// gfx950 only; built by __graft_entry__.build():
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared qcat_hip.hip -o libqcat_hip.so
+//
+// Per batch the library enqueues on the context's stream:
+//   k_pack_windows -> [packed path: k_adapter_packed -> k_job_* -> k_barcode_packed |
+//                      generic path: k_scan_generic] -> k_finalize
+// (see DESIGN.md for the data layout and the roofline of each kernel).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kit.h"
+#include "synth.h"
+
+#include "kit_prepare.inc"
+#include "kernels_common.inc"
+#include "kernels_generic.inc"
+#include "kernels_packed.inc"
+
+using namespace qk;
+
+// ------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int set_err(int rc, const std::string& m) { g_err = m; return rc; }
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return set_err(QCAT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+extern "C" const char* qcat_last_error(void) { return g_err.c_str(); }
+extern "C" int qcat_abi_version(void) { return QCAT_ABI_VERSION; }
+extern "C" int qcat_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// kit
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_DEVICES = 16;
+
+struct DevSynthTpl { qsynth::Tpl t; };
+
+struct KitOnDevice {
+    bool ready = false;
+    DevKit* kit = nullptr;
+    uint8_t* codes = nullptr;
+    int32_t* ids = nullptr;
+    uint32_t* tables = nullptr;
+    char* ascii = nullptr;
+};
+
+struct qcat_kit {
+    HostKit hk;
+    std::mutex mu;
+    KitOnDevice dev[MAX_DEVICES];
+};
+
+extern "C" int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {
+    if (!out) return set_err(QCAT_ERR_ARG, "qcat_kit_create: null output pointer");
+    qcat_kit* k = new qcat_kit();
+    std::string err;
+    int rc = kit_prepare(desc, &k->hk, &err);
+    if (rc) { delete k; return set_err(rc, err); }
+    *out = k;
+    return 0;
+}
+
+extern "C" void qcat_kit_destroy(qcat_kit* k) {
+    if (!k) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < MAX_DEVICES; ++d) {
+        KitOnDevice& kd = k->dev[d];
+        if (!kd.ready) continue;
+        (void)hipSetDevice(d);
+        (void)hipFree(kd.kit); (void)hipFree(kd.codes); (void)hipFree(kd.ids);
+        (void)hipFree(kd.tables); (void)hipFree(kd.ascii);
+    }
+    (void)hipSetDevice(cur);
+    delete k;
+}
+
+extern "C" int qcat_kit_count_buckets(const qcat_kit* k) { return k ? k->hk.dk.n_buckets : QCAT_ERR_ARG; }
+
+static int kit_on_device(qcat_kit* k, int device, KitOnDevice** out) {
+    if (device < 0 || device >= MAX_DEVICES) return set_err(QCAT_ERR_ARG, "device index out of range");
+    std::lock_guard<std::mutex> lock(k->mu);
+    KitOnDevice& kd = k->dev[device];
+    if (!kd.ready) {
+        const HostKit& h = k->hk;
+        HIPCHK(hipMalloc((void**)&kd.kit, sizeof(DevKit)));
+        HIPCHK(hipMalloc((void**)&kd.codes, h.codes.size()));
+        HIPCHK(hipMalloc((void**)&kd.ids, h.ids.size() * 4));
+        HIPCHK(hipMalloc((void**)&kd.tables, h.tables.size() * 4));
+        HIPCHK(hipMalloc((void**)&kd.ascii, std::max<size_t>(1, h.ascii.size())));
+        HIPCHK(hipMemcpy(kd.kit, &h.dk, sizeof(DevKit), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(kd.codes, h.codes.data(), h.codes.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(kd.ids, h.ids.data(), h.ids.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(kd.tables, h.tables.data(), h.tables.size() * 4, hipMemcpyHostToDevice));
+        if (!h.ascii.empty()) HIPCHK(hipMemcpy(kd.ascii, h.ascii.data(), h.ascii.size(), hipMemcpyHostToDevice));
+        kd.ready = true;
+    }
+    *out = &kd;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// batch (reads resident in device memory)
+// ------------------------------------------------------------------------------------------
+struct qcat_batch {
+    int device = 0;
+    uint32_t n_reads = 0;
+    uint64_t n_bases = 0;
+    uint8_t* bases = nullptr;      // n_bases (+16 slack)
+    uint64_t* offsets = nullptr;   // n_reads + 1
+};
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+constexpr int MAX_TIMED = 12;
+
+struct qcat_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // per-scan buffers (grown on demand)
+    size_t cap_win = 0, cap_wlen = 0, cap_recs = 0, cap_reads = 0, cap_buckets = 0;
+    uint8_t* win = nullptr;
+    int32_t* wlen = nullptr;
+    EndRec* recs = nullptr;
+    qcat_result* results = nullptr;
+    unsigned long long* counts = nullptr;
+    PackedScratch packed;
+    uint32_t last_n_reads = 0;
+    int last_buckets = 0;
+    // debug buffers
+    int32_t* dbg_tpl = nullptr; size_t cap_dbg_tpl = 0;
+    int16_t* dbg_rows = nullptr; size_t cap_dbg_rows = 0;
+    // timing
+    bool timing = false;
+    int force_generic = 0;
+    int n_timed = 0;
+    const char* timed_name[MAX_TIMED];
+    hipEvent_t ev[MAX_TIMED + 1];
+    bool ev_ready = false;
+};
+
+extern "C" int qcat_ctx_create(int device, qcat_ctx** out) {
+    if (!out) return set_err(QCAT_ERR_ARG, "qcat_ctx_create: null output pointer");
+    int n = qcat_device_count();
+    if (n <= 0) return set_err(QCAT_ERR_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n || device >= MAX_DEVICES) return set_err(QCAT_ERR_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    qcat_ctx* c = new qcat_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return set_err(QCAT_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    const char* fg = getenv("QCAT_HIP_FORCE_GENERIC");
+    c->force_generic = (fg && fg[0] == '1') ? 1 : 0;
+    *out = c;
+    return 0;
+}
+
+extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->recs); (void)hipFree(c->results);
+    (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows);
+    packed_scratch_free(&c->packed);
+    if (c->ev_ready) for (int i = 0; i <= MAX_TIMED; ++i) (void)hipEventDestroy(c->ev[i]);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int qcat_ctx_set_timing(qcat_ctx* c, int enabled) {
+    if (!c) return set_err(QCAT_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    if (enabled && !c->ev_ready) {
+        for (int i = 0; i <= MAX_TIMED; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+        c->ev_ready = true;
+    }
+    c->timing = enabled != 0;
+    return 0;
+}
+
+template <class T>
+static int grow(T** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return 0;
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    size_t n = std::max<size_t>(need, 1);
+    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    if (e != hipSuccess) { *cap = 0; return set_err(QCAT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    *cap = n;
+    return 0;
+}
+
+static void mark(qcat_ctx* c, const char* name) {
+    if (!c->timing || c->n_timed >= MAX_TIMED) return;
+    c->timed_name[c->n_timed] = name;
+    (void)hipEventRecord(c->ev[c->n_timed + 1], c->stream);
+    c->n_timed++;
+}
+
+// core: scan a resident batch.  dbg: optional debug buffers sized by the caller.
+static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, bool debug, uint32_t row_stride) {
+    if (!c || !kit || !b) return set_err(QCAT_ERR_ARG, "null argument");
+    if (b->device != c->device) return set_err(QCAT_ERR_ARG, "batch lives on another device than the context");
+    HIPCHK(hipSetDevice(c->device));
+    KitOnDevice* kd = nullptr;
+    int rc = kit_on_device(kit, c->device, &kd);
+    if (rc) return rc;
+    const DevKit& hk = kit->hk.dk;
+    const int ends = hk.ends == QCAT_ENDS_5P ? 1 : 2;
+    const uint32_t n = b->n_reads;
+    const size_t n_ends = (size_t)n * ends;
+    if (n_ends >= (1ull << 31)) return set_err(QCAT_ERR_UNSUPPORTED, "batch too large (>= 2^31 read ends)");
+
+    if ((rc = grow(&c->win, &c->cap_win, n_ends * WIN_STRIDE))) return rc;
+    if ((rc = grow(&c->wlen, &c->cap_wlen, n_ends))) return rc;
+    if ((rc = grow(&c->recs, &c->cap_recs, n_ends))) return rc;
+    if ((rc = grow(&c->results, &c->cap_reads, (size_t)n))) return rc;
+    if ((rc = grow(&c->counts, &c->cap_buckets, (size_t)hk.n_buckets))) return rc;
+    if (debug) {
+        if ((rc = grow(&c->dbg_tpl, &c->cap_dbg_tpl, n_ends * 2 * MAX_T))) return rc;
+        if (row_stride && (rc = grow(&c->dbg_rows, &c->cap_dbg_rows, n_ends * 2 * row_stride))) return rc;
+        HIPCHK(hipMemsetAsync(c->dbg_tpl, 0, n_ends * 2 * MAX_T * 4, c->stream));
+        if (row_stride) HIPCHK(hipMemsetAsync(c->dbg_rows, 0x80, n_ends * 2 * row_stride * 2, c->stream));
+    }
+    c->last_n_reads = n;
+    c->last_buckets = hk.n_buckets;
+    c->n_timed = 0;
+    HIPCHK(hipMemsetAsync(c->counts, 0, (size_t)hk.n_buckets * 8, c->stream));
+    if (n == 0) return 0;
+    if (c->timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));
+
+    KitPtrs kp{kd->kit, kd->codes, kd->ids, kd->tables};
+    {
+        uint64_t threads = (uint64_t)n_ends * (WIN_STRIDE / 16);
+        uint32_t blocks = (uint32_t)((threads + 255) / 256);
+        hipLaunchKernelGGL(k_pack_windows, dim3(blocks), dim3(256), 0, c->stream,
+                           b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen);
+        mark(c, "k_pack_windows");
+    }
+    const bool use_packed = hk.fast_ok && !c->force_generic && packed_supported(hk);
+    if (use_packed) {
+        rc = packed_scan(c->stream, kp, hk, c->win, c->wlen, (uint32_t)n_ends, c->recs, &c->packed,
+                         debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride,
+                         [&](const char* nm) { mark(c, nm); });
+        if (rc) return set_err(rc, packed_last_error());
+    } else {
+        uint32_t blocks = (uint32_t)((n_ends + GEN_THREADS - 1) / GEN_THREADS);
+        hipLaunchKernelGGL(k_scan_generic, dim3(blocks), dim3(GEN_THREADS), 0, c->stream,
+                           kp, c->win, c->wlen, (uint32_t)n_ends, c->recs,
+                           debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride);
+        mark(c, "k_scan_generic");
+    }
+    {
+        uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, c->stream,
+                           kp, c->recs, b->offsets, n, c->results, c->counts);
+        mark(c, "k_finalize");
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int qcat_scan_resident(qcat_ctx* c, const qcat_kit* kit, const qcat_batch* b) {
+    return scan_resident_impl(c, const_cast<qcat_kit*>(kit), b, false, 0);
+}
+
+extern "C" int qcat_ctx_synchronize(qcat_ctx* c) {
+    if (!c) return set_err(QCAT_ERR_ARG, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int qcat_ctx_fetch_results(qcat_ctx* c, qcat_result* out, uint32_t n_reads) {
+    if (!c || !out) return set_err(QCAT_ERR_ARG, "null argument");
+    if (n_reads != c->last_n_reads) return set_err(QCAT_ERR_ARG, "n_reads does not match the last scan");
+    HIPCHK(hipSetDevice(c->device));
+    if (n_reads) HIPCHK(hipMemcpyAsync(out, c->results, (size_t)n_reads * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int qcat_ctx_fetch_counts(qcat_ctx* c, int64_t* counts, int32_t n_buckets) {
+    if (!c || !counts) return set_err(QCAT_ERR_ARG, "null argument");
+    if (n_buckets != c->last_buckets) return set_err(QCAT_ERR_ARG, "bucket count does not match the last scan");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(counts, c->counts, (size_t)n_buckets * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" void* qcat_ctx_counts_devptr(qcat_ctx* c) { return c ? c->counts : nullptr; }
+extern "C" void* qcat_ctx_results_devptr(qcat_ctx* c) { return c ? c->results : nullptr; }
+
+extern "C" int qcat_ctx_last_timing(qcat_ctx* c, const char** names, float* ms, int cap) {
+    if (!c) return set_err(QCAT_ERR_ARG, "null context");
+    if (!c->timing) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int n = std::min(cap, c->n_timed);
+    for (int i = 0; i < n; ++i) {
+        names[i] = c->timed_name[i];
+        HIPCHK(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
+// batches: upload / download / synthetic
+// ------------------------------------------------------------------------------------------
+extern "C" void qcat_batch_destroy(qcat_batch* b) {
+    if (!b) return;
+    int cur = 0; (void)hipGetDevice(&cur);
+    (void)hipSetDevice(b->device);
+    (void)hipFree(b->bases); (void)hipFree(b->offsets);
+    (void)hipSetDevice(cur);
+    delete b;
+}
+
+extern "C" int qcat_batch_info(const qcat_batch* b, uint32_t* n_reads, uint64_t* n_bases) {
+    if (!b) return set_err(QCAT_ERR_ARG, "null batch");
+    if (n_reads) *n_reads = b->n_reads;
+    if (n_bases) *n_bases = b->n_bases;
+    return 0;
+}
+
+extern "C" int qcat_batch_upload(qcat_ctx* c, const uint8_t* bases, const uint64_t* offsets,
+                                 uint32_t n_reads, qcat_batch** out) {
+    if (!c || !offsets || !out || (!bases && n_reads && offsets[n_reads] > 0))
+        return set_err(QCAT_ERR_ARG, "qcat_batch_upload: null argument");
+    if (offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
+    for (uint32_t r = 0; r < n_reads; ++r)
+        if (offsets[r + 1] < offsets[r]) return set_err(QCAT_ERR_ARG, "offsets must be non-decreasing");
+    HIPCHK(hipSetDevice(c->device));
+    qcat_batch* b = new qcat_batch();
+    b->device = c->device; b->n_reads = n_reads; b->n_bases = offsets[n_reads];
+    hipError_t e1 = hipMalloc((void**)&b->bases, b->n_bases + 16);
+    hipError_t e2 = hipMalloc((void**)&b->offsets, ((size_t)n_reads + 1) * 8);
+    if (e1 != hipSuccess || e2 != hipSuccess) { qcat_batch_destroy(b); return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch"); }
+    if (b->n_bases) HIPCHK(hipMemcpyAsync(b->bases, bases, b->n_bases, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(b->offsets, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = b;
+    return 0;
+}
+
+extern "C" int qcat_batch_download(qcat_ctx* c, const qcat_batch* b, uint8_t* bases, uint64_t* offsets) {
+    if (!c || !b) return set_err(QCAT_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (offsets) HIPCHK(hipMemcpyAsync(offsets, b->offsets, ((size_t)b->n_reads + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (bases && b->n_bases) HIPCHK(hipMemcpyAsync(bases, b->bases, b->n_bases, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// --- synthetic reads ------------------------------------------------------------------------
+struct SynthSetup {
+    qsynth::Params p;
+    qsynth::Tpl t5, t3;
+    bool has5 = false, has3 = false;
+};
+
+static int synth_setup(const HostKit& hk, const qcat_synth_params* sp, const char* ascii_base, SynthSetup* s, std::string* err) {
+    if (!sp) { *err = "null synth params"; return QCAT_ERR_ARG; }
+    if (sp->lead_max < sp->lead_min) { *err = "lead_max < lead_min"; return QCAT_ERR_ARG; }
+    if (sp->error_rate < 0.f || sp->error_rate > 1.f || sp->no_adapter_fraction < 0.f || sp->no_adapter_fraction > 1.f) {
+        *err = "rates must be in [0,1]"; return QCAT_ERR_ARG;
+    }
+    s->p.seed = sp->seed; s->p.insert_len = sp->insert_len; s->p.lead_min = sp->lead_min; s->p.lead_max = sp->lead_max;
+    s->p.thr_err = (uint32_t)(sp->error_rate * 16777216.0f);
+    s->p.thr_none = (uint32_t)(sp->no_adapter_fraction * 16777216.0f);
+    auto fill = [&](int t, qsynth::Tpl* o) -> bool {
+        if (t < 0) return false;
+        const DevTpl& p = hk.dk.tpl[t];
+        o->seq = ascii_base + hk.ascii_tpl_off[t]; o->len = p.len;
+        for (int i = 0; i < 2; ++i) {
+            o->bc_start[i] = hk.bc_start[t][i]; o->bc_len[i] = p.sets[i].n > 0 ? p.bc_len[i] : 0;
+            o->n[i] = p.sets[i].n;
+            o->sets[i] = p.sets[i].n > 0 ? ascii_base + hk.ascii_set_off[t][i] : nullptr;
+        }
+        return true;
+    };
+    if (sp->tpl_5p >= hk.dk.nt || sp->tpl_3p >= hk.dk.nt) { *err = "synth template index out of range"; return QCAT_ERR_ARG; }
+    s->has5 = fill(sp->tpl_5p, &s->t5);
+    s->has3 = fill(sp->tpl_3p, &s->t3);
+    return 0;
+}
+
+extern "C" int64_t qcat_synth_read(const qcat_kit* kit, const qcat_synth_params* sp, uint64_t index,
+                                   uint8_t* buf, uint64_t cap) {
+    if (!kit) return set_err(QCAT_ERR_ARG, "null kit");
+    SynthSetup s; std::string err;
+    int rc = synth_setup(kit->hk, sp, kit->hk.ascii.data(), &s, &err);
+    if (rc) return set_err(rc, err);
+    qsynth::StoreSink sink(buf, buf ? cap : 0);
+    qsynth::generate(s.p, index, s.has5 ? &s.t5 : nullptr, s.has3 ? &s.t3 : nullptr, sink);
+    return (int64_t)sink.n;
+}
+
+__global__ void k_synth_lengths(qsynth::Params p, qsynth::Tpl t5, qsynth::Tpl t3, int has5, int has3,
+                                uint64_t first, uint32_t n, uint64_t* lens) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    qsynth::CountSink sink;
+    qsynth::generate(p, first + i, has5 ? &t5 : nullptr, has3 ? &t3 : nullptr, sink);
+    lens[i] = sink.n;
+}
+
+__global__ void k_synth_write(qsynth::Params p, qsynth::Tpl t5, qsynth::Tpl t3, int has5, int has3,
+                              uint64_t first, uint32_t n, const uint64_t* offsets, uint8_t* bases) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    qsynth::StoreSink sink(bases + offsets[i], offsets[i + 1] - offsets[i]);
+    qsynth::generate(p, first + i, has5 ? &t5 : nullptr, has3 ? &t3 : nullptr, sink);
+}
+
+extern "C" int qcat_batch_synthesize(qcat_ctx* c, const qcat_kit* ckit, const qcat_synth_params* sp, qcat_batch** out) {
+    if (!c || !ckit || !sp || !out) return set_err(QCAT_ERR_ARG, "null argument");
+    qcat_kit* kit = const_cast<qcat_kit*>(ckit);
+    HIPCHK(hipSetDevice(c->device));
+    KitOnDevice* kd = nullptr;
+    int rc = kit_on_device(kit, c->device, &kd);
+    if (rc) return rc;
+    SynthSetup s; std::string err;
+    if ((rc = synth_setup(kit->hk, sp, kd->ascii, &s, &err))) return set_err(rc, err);
+    const uint32_t n = sp->n_reads;
+    uint64_t* d_lens = nullptr;
+    HIPCHK(hipMalloc((void**)&d_lens, ((size_t)n + 1) * 8));
+    uint32_t blocks = (n + 255) / 256;
+    // the read index space is global: `seed` identifies the data set, reads [first, first+n) are
+    // produced here (first = 0; shards pass distinct seeds or use qcat_synth_read for offsets)
+    if (n) hipLaunchKernelGGL(k_synth_lengths, dim3(blocks), dim3(256), 0, c->stream, s.p, s.t5, s.t3,
+                              (int)s.has5, (int)s.has3, (uint64_t)0, n, d_lens);
+    std::vector<uint64_t> lens((size_t)n + 1, 0), offs((size_t)n + 1, 0);
+    if (n) HIPCHK(hipMemcpyAsync(lens.data(), d_lens, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n; ++i) offs[i + 1] = offs[i] + lens[i];
+    qcat_batch* b = new qcat_batch();
+    b->device = c->device; b->n_reads = n; b->n_bases = offs[n];
+    hipError_t e1 = hipMalloc((void**)&b->bases, b->n_bases + 16);
+    hipError_t e2 = hipMalloc((void**)&b->offsets, ((size_t)n + 1) * 8);
+    if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(d_lens); qcat_batch_destroy(b); return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for synthetic batch"); }
+    HIPCHK(hipMemcpyAsync(b->offsets, offs.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (n) hipLaunchKernelGGL(k_synth_write, dim3(blocks), dim3(256), 0, c->stream, s.p, s.t5, s.t3,
+                              (int)s.has5, (int)s.has3, (uint64_t)0, n, b->offsets, b->bases);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_lens);
+    HIPCHK(hipGetLastError());
+    *out = b;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-buffer entry points
+// ------------------------------------------------------------------------------------------
+static void fill_trace(const HostKit& hk, const EndRec& r, const int32_t* tplraw, const int32_t* tplend, qcat_end_trace* t) {
+    memset(t, 0, sizeof *t);
+    t->window_len = r.window_len;
+    for (int i = 0; i < MAX_T; ++i) { t->tpl_raw[i] = tplraw[i]; t->tpl_end[i] = tplend[i]; }
+    t->best_tpl = r.best_tpl; t->best_end = r.best_end; t->best_raw = r.best_raw; t->used_tpl = r.used_tpl;
+    t->region_path = r.region_path;
+    for (int s = 0; s < 2; ++s) {
+        t->region_start[s] = r.region_start[s]; t->region_len[s] = r.region_len[s];
+        t->bc_idx[s] = r.bc_idx[s]; t->bc_raw[s] = r.bc_raw[s];
+    }
+    const DevTpl& p = hk.dk.tpl[r.used_tpl];
+    if (hk.dk.mode == QCAT_MODE_EPI2ME) {
+        int ae = r.best_end + p.trim_offset;
+        t->adapter_end = ae > r.window_len ? r.window_len : ae;
+    } else {
+        t->adapter_end = (r.bc_idx[0] >= 0 && r.bc_idx[1] >= 0) ? r.best_end : 0;
+    }
+}
+
+extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
+                               const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                               qcat_result* out, int64_t* counts,
+                               qcat_end_trace* traces, int16_t* bc_rows, uint32_t row_stride) {
+    if (!c || !ckit || !offsets || !out) return set_err(QCAT_ERR_ARG, "null argument");
+    qcat_kit* kit = const_cast<qcat_kit*>(ckit);
+    if (bc_rows) {
+        int need = 0;
+        for (int t = 0; t < kit->hk.dk.nt; ++t)
+            for (int s = 0; s < 2; ++s) need = std::max(need, kit->hk.dk.tpl[t].sets[s].n);
+        if ((int)row_stride < need) return set_err(QCAT_ERR_ARG, "row_stride smaller than the largest barcode set");
+    }
+    qcat_batch* b = nullptr;
+    int rc = qcat_batch_upload(c, bases, offsets, n_reads, &b);
+    if (rc) return rc;
+    const bool debug = traces != nullptr || bc_rows != nullptr;
+    rc = scan_resident_impl(c, kit, b, debug, bc_rows ? row_stride : 0);
+    if (!rc) rc = qcat_ctx_fetch_results(c, out, n_reads);
+    if (!rc && counts) {
+        std::vector<int64_t> tmp((size_t)kit->hk.dk.n_buckets);
+        rc = qcat_ctx_fetch_counts(c, tmp.data(), kit->hk.dk.n_buckets);
+        if (!rc) for (size_t i = 0; i < tmp.size(); ++i) counts[i] += tmp[i];
+    }
+    if (!rc && debug && n_reads) {
+        const int ends = kit->hk.dk.ends == QCAT_ENDS_5P ? 1 : 2;
+        const size_t n_ends = (size_t)n_reads * ends;
+        std::vector<EndRec> recs(n_ends);
+        std::vector<int32_t> tpl(n_ends * 2 * MAX_T);
+        hipError_t e = hipMemcpy(recs.data(), c->recs, n_ends * sizeof(EndRec), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(tpl.data(), c->dbg_tpl, tpl.size() * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && bc_rows) e = hipMemcpy(bc_rows, c->dbg_rows, n_ends * 2 * row_stride * 2, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = set_err(QCAT_ERR_DEVICE, std::string("debug download: ") + hipGetErrorString(e));
+        else if (traces)
+            for (size_t i = 0; i < n_ends; ++i)
+                fill_trace(kit->hk, recs[i], &tpl[(i * 2 + 0) * MAX_T], &tpl[(i * 2 + 1) * MAX_T], &traces[i]);
+    }
+    qcat_batch_destroy(b);
+    return rc;
+}
+
+extern "C" int qcat_scan_batch(qcat_ctx* c, const qcat_kit* kit,
+                               const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                               qcat_result* out, int64_t* counts) {
+    return qcat_scan_debug(c, kit, bases, offsets, n_reads, out, counts, nullptr, nullptr, 0);
+}

@@ -1,0 +1,140 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against
+  (a) the committed golden vectors of the reference's own Python (record + per-end trace +
+      every per-barcode raw score), and
+  (b) the CPU oracle on seeded synthetic batches at sizes the oracle finishes in seconds,
+bit-exact (integer path: no tolerance)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+import oracle_lib
+import synth
+from qcat_amd import config, native, scanner
+
+pytestmark = pytest.mark.gpu
+
+CASES = [c["name"] for c in helpers.golden()["cases"]]
+_ctx = {}
+
+
+def ctx():
+    if "c" not in _ctx:
+        _ctx["c"] = native.NativeContext(0)
+    return _ctx["c"]
+
+
+def hip_scan(det, reads, ends=native.ENDS_BOTH, trace=True, cfg=None):
+    d = det.descriptor(qcat_config=cfg, ends=ends)
+    kit = native.NativeKit(d)
+    bases, offsets = native.pack_reads(reads)
+    cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+    if trace:
+        recs, traces, rows = ctx().scan(kit, bases, offsets, counts=cnt, trace=True, rows=True)
+    else:
+        recs, traces, rows = ctx().scan(kit, bases, offsets, counts=cnt), None, None
+    return d, recs, traces, rows, cnt
+
+
+def assert_same_as_oracle(d, reads, recs, traces, rows, cnt):
+    o_recs, o_cnt, o_traces, o_rows = oracle_lib.scan(d, reads, counts=True, trace=True, rows=True, threads=8)
+    assert recs.tobytes() == o_recs.tobytes()
+    assert np.array_equal(cnt, o_cnt)
+    if traces is not None:
+        for name in native.TRACE_DTYPE.names:
+            assert np.array_equal(traces[name], o_traces[name]), name
+        assert np.array_equal(rows, o_rows)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_case(name):
+    case = [c for c in helpers.golden()["cases"] if c["name"] == name][0]
+    det = helpers.make_scanner(case["mode"], case["kit"])
+    reads = helpers.case_reads(case, det.layouts)
+    d, recs, traces, rows, cnt = hip_scan(det, reads)
+    helpers.assert_case_matches(case, recs, traces, rows, det.layouts)
+    assert_same_as_oracle(d, reads, recs, traces, rows, cnt)
+
+
+def test_scan_5p_only_golden():
+    g = helpers.golden()["scan5p"]
+    det = scanner.factory(kit=g["kit"])
+    reads = helpers.case_reads({"gen": g["gen"]}, det.layouts)
+    d, recs, traces, rows, cnt = hip_scan(det, reads, ends=native.ENDS_5P)
+    for rec, want in zip(recs, g["results"]):
+        assert helpers.record_as_golden(rec, det.layouts, "epi2me") == want
+    o = oracle_lib.scan(d, reads)
+    assert recs.tobytes() == o.tobytes()
+
+
+@pytest.mark.parametrize("mode,kit,t5,t3,e,n", [
+    ("epi2me", "NBD103/NBD104", 1, 0, 0.08, 3000),
+    ("epi2me", "PBC096", 1, 0, 0.0, 1500),
+    ("epi2me", "PBC096", 1, 0, 0.08, 1500),
+    ("epi2me", "PBC096", 1, 0, 0.25, 600),
+    ("epi2me", "PBK004/LWB001", 1, 0, 0.12, 1500),
+    ("epi2me", "RBK004", 0, -1, 0.1, 800),
+    ("epi2me", "VMK001", 0, -1, 0.1, 800),
+    ("epi2me", "RAB204/RAB214", 1, 0, 0.1, 600),
+    ("epi2me", None, 3, 2, 0.08, 400),
+    ("dual", None, 1, 0, 0.08, 800),
+    ("dual", None, 1, 0, 0.2, 400),
+    ("epi2me", "DUAL", 1, 0, 0.08, 300),
+])
+def test_synthetic_vs_oracle(mode, kit, t5, t3, e, n):
+    det = helpers.make_scanner(mode, kit)
+    reads = synth.synth_batch(n, 1234567 + n, det.layouts, t5, t3, error_rate=e)
+    d, recs, traces, rows, cnt = hip_scan(det, reads)
+    assert_same_as_oracle(d, reads, recs, traces, rows, cnt)
+    assert cnt.sum() == 2 * n
+
+
+def test_ragged_and_degenerate_reads():
+    det = scanner.factory(kit="PBC096")
+    body = synth.synth_read(3, 5, det.layouts, 1, 0, error_rate=0.05)
+    reads = ["", "A", "AC", "N" * 10, "n" * 300, body[:1], body[:38], body[:149], body[:150], body[:151],
+             body[:299], body[:300], body, body.lower(), "R" * 200, body[:60] + "N" * 30 + body[90:],
+             "*" * 40, body[:75] * 2]
+    reads = reads * 5 + [body[:k] for k in range(0, 200, 3)]
+    d, recs, traces, rows, cnt = hip_scan(det, reads)
+    assert_same_as_oracle(d, reads, recs, traces, rows, cnt)
+
+
+def test_non_default_config_takes_the_generic_device_path():
+    """Affine gaps (open != extend) and a shorter window are valid qcat configurations the
+    packed kernels do not cover: they must still run on the GPU and match the oracle."""
+    cfg = config.qcatConfig()
+    cfg.gap_open = 3
+    cfg.gap_extend = 1
+    cfg.max_align_length = 120
+    cfg.extracted_barcode_extension = 7
+    cfg.barcode_context_length = 9
+    det = scanner.factory(kit="NBD103/NBD104")
+    reads = synth.synth_batch(300, 99, det.layouts, 1, 0, error_rate=0.1)
+    d, recs, traces, rows, cnt = hip_scan(det, reads, cfg=cfg)
+    assert_same_as_oracle(d, reads, recs, traces, rows, cnt)
+
+
+def test_scanner_api_returns_reference_shaped_dicts():
+    inl = helpers.inline_reads()
+    det = scanner.factory(kit="RBK001")
+    res = det.detect_barcode(inl["read"])
+    assert set(res) == {"barcode", "barcode_score", "adapter", "adapter_end", "trim5p", "trim3p", "exit_status"}
+    assert res["barcode"].name == "barcode02" and res["adapter"].kit == "RBK001"
+    assert res["barcode_score"] == 100.0 and res["adapter_end"] == 101 and (res["trim5p"], res["trim3p"]) == (101, 993)
+    assert det.detect_barcode("")["barcode"] is None
+    five = [inl[n] for n in ("read", "read_bc3_exact", "read_bc3", "real_bc03_porechop", "read_nobc")]
+    batch = det.detect_barcode_batch(five, [None] * 5)
+    want = [b for b in helpers.golden()["batch"] if b["kit"] == "RBK001"][0]["results"]
+    for got, w in zip(batch, want):
+        assert (got["barcode"].name if got["barcode"] else None) == w["barcode_name"]
+        assert float(got["barcode_score"]).hex() == w["score_hex"]
+        assert (got["adapter_end"], got["trim5p"], got["trim3p"], got["exit_status"]) == \
+               (w["adapter_end"], w["trim5p"], w["trim3p"], w["exit_status"])
+    # R7: the default read_qualities=[None] truncates the batch to one read
+    assert len(det.detect_barcode_batch(five)) == 1
+    dual = scanner.factory(mode="dual")
+    r = dual.detect_barcode(inl["real_double_barcode_read"])
+    assert r["barcode"].name == "barcode06/95" and r["barcode"].id == "6/95"
+    assert r["barcode_score"] == 84.78260869565217
