@@ -239,7 +239,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         if ((rc = grow(&c->dbg_tpl, &c->cap_dbg_tpl, n_ends * 2 * MAX_T))) return rc;
         if (row_stride && (rc = grow(&c->dbg_rows, &c->cap_dbg_rows, n_ends * 2 * row_stride))) return rc;
         HIPCHK(hipMemsetAsync(c->dbg_tpl, 0, n_ends * 2 * MAX_T * 4, c->stream));
-        if (row_stride) HIPCHK(hipMemsetAsync(c->dbg_rows, 0x80, n_ends * 2 * row_stride * 2, c->stream));
+        if (row_stride) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)c->dbg_rows, (unsigned short)0x8000, n_ends * 2 * row_stride, c->stream));
     }
     c->last_n_reads = n;
     c->last_buckets = hk.n_buckets;
