@@ -24,12 +24,26 @@ constexpr int MAX_TARGET = QCAT_MAX_TARGET_LEN;
 constexpr int MAX_WIN = QCAT_MAX_WINDOW;
 constexpr int WIN_STRIDE = 160;          // bytes per packed code window (16-B aligned rows)
 constexpr int RAW_NEVER = 1 << 20;       // "no raw score passes"
+constexpr int PADMAX = 8;                // most leading padding columns a width class may have
+
+// width classes of the packed kernels (must match tools/gen_cols.py); 0 = not supported
+inline int adapter_width_class(int len) {
+    const int w[] = {40, 48, 56, 60, 64, 84, 92, 104, 112, 120, 128};
+    for (int v : w) if (len <= v && v - len <= PADMAX) return v;
+    return 0;
+}
+inline int barcode_width_class(int len) {
+    const int w[] = {40, 44, 48, 56, 64};
+    for (int v : w) if (len <= v && v - len <= PADMAX) return v;
+    return 0;
+}
 
 struct DevSet {
     int32_t n, blen, tlen, uplen, downlen;
     int32_t tgt_off;            // codes blob: n * tlen target codes (up + barcode + down)
     int32_t ids_off;            // ids blob: n dense ids
-    int32_t tbl_off;            // tables blob: n * tlen dwords (fast path), -1 if not eligible
+    int32_t tbl_off;            // tables blob: n rows of `width` dwords, right-aligned (-1: not eligible)
+    int32_t width;              // register-array width class of the packed barcode kernel
     int32_t min_raw_pass;       // smallest raw with raw*100.0/tlen >= min_quality
     int32_t min_raw_conflict;   // smallest raw with raw*100.0/tlen >= conflict_min_score
 };
@@ -39,7 +53,8 @@ struct DevTpl {
     int32_t bc_end[2], bc_len[2];
     int32_t region_min_raw;     // smallest raw with raw*100.0/den > region_min_adapter_score
     int32_t code_off;           // codes blob: len template codes
-    int32_t tbl_off;            // tables blob: len dwords (fast path), -1 if not eligible
+    int32_t tbl_off;            // tables blob: `width` dwords, right-aligned (-1: not eligible)
+    int32_t width;              // register-array width class of the packed adapter kernel
     DevSet sets[2];
 };
 
