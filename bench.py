@@ -213,8 +213,11 @@ def main():
             out["parity"] = {"checked_reads": n_sample, "mismatches_vs_oracle": mism}
             out["valu"] = {"dp_cells_per_read": round(cells_per_read, 1),
                            "cell_updates_per_s": round(value * cells_per_read, 1),
-                           "peak_u16x2_cells_per_s": 256 * 4 * 32 * 2.4e9 * 2 / 4,
-                           "note": "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz x 2 cells / 4 VALU ops per packed cell pair"}
+                           "peak_cells_per_s": 256 * 4 * 2.4e9 * 128 / 14.0,
+                           "frac_of_valu_peak": round(value * cells_per_read / (256 * 4 * 2.4e9 * 128 / 14.0), 4),
+                           "note": "VALU-issue ceiling of the packed kernel: per column one wave retires 128 cells with "
+                                   "v_perm_b32 (4 cyc) + v_add_u32 (2) + 2 x v_pk_max_u16 (4+4) = 14 cycles/SIMD "
+                                   "(issue rates measured by tools/valu_rate.hip), 1024 SIMDs, 2.4 GHz nominal"}
         print(json.dumps(out))
         sys.stdout.flush()
     lib.qcat_batch_destroy(batch)

@@ -270,7 +270,9 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         mark(c, "k_scan_generic");
     }
     {
-        uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 4096);
+        // every block zeroes and flushes an LDS histogram of n_buckets entries: fewer, fatter blocks
+        // when the bucket vector is long (dual kits)
+        uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, hk.n_buckets > 2048 ? 512 : 4096);
         hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, c->stream,
                            kp, c->recs, b->offsets, n, c->results, c->counts);
         mark(c, "k_finalize");
