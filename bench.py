@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 from qcat_amd import config as qconfig  # noqa: E402
-from qcat_amd import native, scanner  # noqa: E402
+from qcat_amd import native, parallel, scanner  # noqa: E402
 
 WORKLOADS = {
     # name: (mode, kit, ends, tpl_5p, tpl_3p, algorithmic bytes per read)
@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--error-rate", type=float, default=0.08)
     ap.add_argument("--seed", type=int, default=20260928 + 1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -63,7 +64,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # torchrun launch (also with one process)
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -91,22 +93,35 @@ def main():
     nr = C.c_uint32()
     hip.check(lib.qcat_batch_info(batch, C.byref(nr), C.byref(nb)))
 
-    counts_t = None
-    if world > 1:
-        counts_t = torch.zeros(n_buckets, dtype=torch.int64, device="cuda")
-        host_counts = np.zeros(n_buckets, dtype=np.int64)
+    state = {"counts_t": None, "zero_copy": None}
 
-    def step(reduce_counts=True):
+    def reduce_counts():
+        # per-barcode / per-kit count vector: the only cross-GPU exchange of the path (RCCL all-reduce,
+        # in place on the library's device-resident int64 vector when torch can view it zero-copy)
+        hip.check(lib.qcat_ctx_synchronize(ctx.handle))          # the library runs on its own stream
+        if state["zero_copy"] is None:
+            try:
+                ptr = lib.qcat_ctx_counts_devptr(ctx.handle)
+                state["counts_t"] = torch.as_tensor(parallel._DevArray(ptr, n_buckets), device="cuda")
+                state["zero_copy"] = state["counts_t"].data_ptr() == ptr
+            except Exception:
+                state["zero_copy"] = False
+            if not state["zero_copy"]:
+                state["counts_t"] = torch.zeros(n_buckets, dtype=torch.int64, device="cuda")
+        if not state["zero_copy"]:
+            host = np.zeros(n_buckets, dtype=np.int64)
+            hip.check(lib.qcat_ctx_fetch_counts(ctx.handle, host.ctypes.data, n_buckets))
+            state["counts_t"].copy_(torch.from_numpy(host))
+        dist.all_reduce(state["counts_t"], op=dist.ReduceOp.SUM)
+
+    def step():
         hip.check(lib.qcat_scan_resident(ctx.handle, kit.handle, batch))
-        if world > 1 and reduce_counts:
-            # per-barcode / per-kit count vector: the only cross-GPU exchange of the path
-            hip.check(lib.qcat_ctx_fetch_counts(ctx.handle, host_counts.ctypes.data, n_buckets))
-            counts_t.copy_(torch.from_numpy(host_counts))
-            dist.all_reduce(counts_t, op=dist.ReduceOp.SUM)
+        if use_dist:
+            reduce_counts()
 
     def sync_all():
         hip.check(lib.qcat_ctx_synchronize(ctx.handle))
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -126,7 +141,7 @@ def main():
             kernel_ms.setdefault(names[i].decode(), []).append(float(ms[i]))
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -134,11 +149,12 @@ def main():
     # ---- results of the last step: parity spot check + counts -------------------------------
     recs = np.zeros(a.reads, dtype=native.RESULT_DTYPE)
     hip.check(lib.qcat_ctx_fetch_results(ctx.handle, recs.ctypes.data, a.reads))
-    cnt = np.zeros(n_buckets, dtype=np.int64)
-    hip.check(lib.qcat_ctx_fetch_counts(ctx.handle, cnt.ctypes.data, n_buckets))
-    total_counts = cnt.copy()
-    if world > 1:
-        total_counts = counts_t.cpu().numpy()
+    if use_dist:
+        torch.cuda.synchronize()
+        total_counts = state["counts_t"].cpu().numpy()
+    else:
+        total_counts = np.zeros(n_buckets, dtype=np.int64)
+        hip.check(lib.qcat_ctx_fetch_counts(ctx.handle, total_counts.ctypes.data, n_buckets))
 
     out = None
     if rank == 0:
@@ -165,7 +181,25 @@ def main():
                           "reads_per_gpu": a.reads, "kit": kit_name or "DUAL", "mode": mode,
                           "n_barcodes": len(det.layouts[0].barcode_set_1), "parallelism": "reads sharded x%d" % world},
                "roofline": roof,
-               "counts_total": int(total_counts[: n_buckets - len(desc.kit_names) - 1].sum())}
+               "counts_total": int(total_counts[: n_buckets - len(desc.kit_names) - 1].sum()),
+               "count_allreduce": ("rccl in place on the device vector" if state["zero_copy"] else
+                                   ("rccl via host staging" if use_dist else "single process"))}
+        if not a.no_host_inclusive:
+            # PCIe-inclusive rate of the host-buffer entry point (never `value`): download the shard,
+            # then time qcat_scan_batch (upload + scan + 24 B/read download) twice, keep the faster.
+            hb = np.zeros(nb.value, dtype=np.uint8)
+            ho = np.zeros(a.reads + 1, dtype=np.uint64)
+            hip.check(lib.qcat_batch_download(ctx.handle, batch, hb.ctypes.data, ho.ctypes.data))
+            hip.check(lib.qcat_ctx_set_timing(ctx.handle, 0))
+            best = None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                ctx.scan(kit, hb, ho)
+                dt = time.perf_counter() - t1
+                best = dt if best is None else min(best, dt)
+            out["host_inclusive"] = {"value": round(a.reads / best, 1), "unit": "reads/s",
+                                     "note": "qcat_scan_batch from pageable host memory: %.0f MB up, %.0f MB down per step"
+                                             % (nb.value / 1e6, a.reads * 24 / 1e6)}
 
         # ---- CPU baseline + parity on a bounded sample of rank 0's shard ---------------------
         if not a.no_cpu_baseline:
@@ -221,7 +255,7 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     lib.qcat_batch_destroy(batch)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

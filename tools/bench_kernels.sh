@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/bench_kernels.sh <workload> [extra bench args] -- prints value + per-kernel ms
-out=$(python bench.py --workload "$1" --no-cpu-baseline "${@:2}" 2>&1 | tail -1)
+out=$(python bench.py --workload "$1" --no-cpu-baseline --no-host-inclusive "${@:2}" 2>&1 | tail -1)
 python - "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[1])

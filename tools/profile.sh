@@ -8,7 +8,7 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-cmd="python $R/bench.py --workload $wl --no-cpu-baseline $*"
+cmd="python $R/bench.py --workload $wl --no-cpu-baseline --no-host-inclusive $*"
 rocprofv3 --kernel-trace --stats -d /tmp/rp_$tag/trace -o trace --output-format csv -- $cmd > $R/$out/bench_under_trace.log 2>&1
 find /tmp/rp_$tag/trace -name "*kernel_stats.csv" -exec cp {} $R/$out/kernel_stats.csv \;
 i=0
