@@ -172,6 +172,16 @@ int  qcat_scan_batch(qcat_ctx* ctx, const qcat_kit* kit,
                      const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                      qcat_result* out, int64_t* counts);
 
+/* replaces: BarcodeScanner.detect_kit (qcat/scanner_base.py:662-678) = per read scan_ends (:632-642):
+ * find_best_adapter_template over ALL templates of `kit` at both ends, the template of the
+ * higher-scoring end (3' on ties) gets the read's vote.  votes[t] += reads voting for template t,
+ * first_read[t] = smallest read index that voted for t (or n_reads): the host folds templates onto
+ * kit names and breaks count ties by first appearance like the reference's dict + stable sort
+ * (:657-660).  `kit` must have been created with QCAT_ENDS_BOTH. */
+int  qcat_detect_kit(qcat_ctx* ctx, const qcat_kit* kit,
+                     const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                     int64_t* votes, int64_t* first_read);
+
 /* Same, plus one qcat_end_trace per scanned read end (2*n_reads entries, 5' then 3' per read;
  * n_reads entries with QCAT_ENDS_5P) and, if bc_rows != NULL, the raw score of EVERY barcode
  * alignment: bc_rows[((end * 2 + set) * row_stride) + b], row_stride >= largest set. */

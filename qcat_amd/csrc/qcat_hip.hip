@@ -217,7 +217,8 @@ static void mark(qcat_ctx* c, const char* name) {
 }
 
 // core: scan a resident batch.  dbg: optional debug buffers sized by the caller.
-static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, bool debug, uint32_t row_stride) {
+static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, bool debug, uint32_t row_stride,
+                              bool adapter_only = false) {
     if (!c || !kit || !b) return set_err(QCAT_ERR_ARG, "null argument");
     if (b->device != c->device) return set_err(QCAT_ERR_ARG, "batch lives on another device than the context");
     HIPCHK(hipSetDevice(c->device));
@@ -260,16 +261,17 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     if (use_packed) {
         rc = packed_scan(c->stream, kp, hk, c->win, c->wlen, (uint32_t)n_ends, c->recs, &c->packed,
                          debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride,
-                         [&](const char* nm) { mark(c, nm); });
+                         [&](const char* nm) { mark(c, nm); }, adapter_only);
         if (rc) return set_err(rc, packed_last_error());
     } else {
         uint32_t blocks = (uint32_t)((n_ends + GEN_THREADS - 1) / GEN_THREADS);
         hipLaunchKernelGGL(k_scan_generic, dim3(blocks), dim3(GEN_THREADS), 0, c->stream,
                            kp, c->win, c->wlen, (uint32_t)n_ends, c->recs,
-                           debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride);
+                           debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride,
+                           adapter_only ? 1 : 0);
         mark(c, "k_scan_generic");
     }
-    {
+    if (!adapter_only) {
         // every block zeroes and flushes an LDS histogram of n_buckets entries: fewer, fatter blocks
         // when the bucket vector is long (dual kits)
         uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, hk.n_buckets > 2048 ? 512 : 4096);
@@ -531,6 +533,45 @@ extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
     }
     qcat_batch_destroy(b);
     return rc;
+}
+
+extern "C" int qcat_detect_kit(qcat_ctx* c, const qcat_kit* ckit, const uint8_t* bases, const uint64_t* offsets,
+                               uint32_t n_reads, int64_t* votes, int64_t* first_read) {
+    if (!c || !ckit || !offsets || !votes || !first_read) return set_err(QCAT_ERR_ARG, "null argument");
+    qcat_kit* kit = const_cast<qcat_kit*>(ckit);
+    if (kit->hk.dk.ends != QCAT_ENDS_BOTH) return set_err(QCAT_ERR_ARG, "qcat_detect_kit needs a kit created with QCAT_ENDS_BOTH");
+    const int nt = kit->hk.dk.nt;
+    std::vector<unsigned long long> hv(MAX_T, 0), hf(MAX_T, ~0ull);
+    qcat_batch* b = nullptr;
+    int rc = qcat_batch_upload(c, bases, offsets, n_reads, &b);
+    if (rc) return rc;
+    rc = scan_resident_impl(c, kit, b, false, 0, true);
+    unsigned long long* d = nullptr;
+    if (!rc && n_reads) {
+        KitOnDevice* kd = nullptr;
+        rc = kit_on_device(kit, c->device, &kd);
+        hipError_t e = hipSuccess;
+        if (!rc) e = hipMalloc((void**)&d, 2 * MAX_T * 8);
+        if (!rc && e == hipSuccess) e = hipMemsetAsync(d, 0, MAX_T * 8, c->stream);
+        if (!rc && e == hipSuccess) e = hipMemsetAsync(d + MAX_T, 0xFF, MAX_T * 8, c->stream);
+        if (!rc && e == hipSuccess) {
+            uint32_t blocks = std::min<uint32_t>((n_reads + 255) / 256, 1024);
+            hipLaunchKernelGGL(k_vote, dim3(blocks), dim3(256), 0, c->stream, kd->kit, c->recs, n_reads, d, d + MAX_T);
+            e = hipMemcpyAsync(hv.data(), d, MAX_T * 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(hf.data(), d + MAX_T, MAX_T * 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        if (!rc && e != hipSuccess) rc = set_err(QCAT_ERR_DEVICE, std::string("qcat_detect_kit: ") + hipGetErrorString(e));
+    }
+    if (d) (void)hipFree(d);
+    qcat_batch_destroy(b);
+    if (rc) return rc;
+    for (int t = 0; t < nt; ++t) {
+        votes[t] += (int64_t)hv[t];
+        int64_t f = hf[t] == ~0ull ? (int64_t)n_reads : (int64_t)hf[t];
+        first_read[t] = f;
+    }
+    return 0;
 }
 
 extern "C" int qcat_scan_batch(qcat_ctx* c, const qcat_kit* kit,

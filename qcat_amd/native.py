@@ -209,6 +209,7 @@ class HipLibrary(object):
             "qcat_ctx_destroy": (None, [vp]),
             "qcat_scan_batch": (C.c_int, [vp, vp, vp, vp, u32, vp, vp]),
             "qcat_scan_debug": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, vp, u32]),
+            "qcat_detect_kit": (C.c_int, [vp, vp, vp, vp, u32, vp, vp]),
             "qcat_batch_upload": (C.c_int, [vp, vp, vp, u32, C.POINTER(vp)]),
             "qcat_batch_synthesize": (C.c_int, [vp, vp, C.POINTER(SynthParams), C.POINTER(vp)]),
             "qcat_batch_destroy": (None, [vp]),
@@ -276,6 +277,16 @@ class NativeContext(object):
         if h:
             self.hip.lib.qcat_ctx_destroy(h)
             self.handle = None
+
+    def detect_kit(self, kit, bases, offsets):
+        """per-template (votes, first voting read) of qcat_detect_kit."""
+        n = len(offsets) - 1
+        nt = len(kit.descriptor.layouts)
+        votes = np.zeros(nt, dtype=np.int64)
+        first = np.zeros(nt, dtype=np.int64)
+        self.hip.check(self.hip.lib.qcat_detect_kit(self.handle, kit.handle, bases.ctypes.data,
+                                                    offsets.ctypes.data, n, votes.ctypes.data, first.ctypes.data))
+        return votes, first
 
     def scan(self, kit, bases, offsets, counts=None, trace=False, rows=False):
         n = len(offsets) - 1

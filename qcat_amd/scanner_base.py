@@ -168,18 +168,31 @@ class BarcodeScanner(object):
         return sorted(adapter_counts.items(), key=operator.itemgetter(1), reverse=True)[0][0]
 
     def detect_kit(self, read_sequences, qcat_config=None):
-        """Per-batch kit vote (``qcat/scanner_base.py:662-678``).  With one kit selected the vote
-        can only return that kit; kit auto needs the native vote kernel."""
-        kits = []
-        for l in self.layouts:
-            if l.kit not in kits:
-                kits.append(l.kit)
-        if not read_sequences or not kits:
+        """Per-batch kit vote (``qcat/scanner_base.py:662-678``): every read votes for the kit of
+        the adapter template that scores best at its better end (``scan_ends``, ``:632-642``); the
+        alignments run on the GPU (``qcat_detect_kit``), the fold onto kit names and the
+        first-appearance tie-break of the reference's dict + stable sort stay here."""
+        if qcat_config is None:
+            qcat_config = config.qcatConfig()
+        if not read_sequences:
             return None, []
-        if len(kits) == 1:
-            return kits[0], []
-        raise NotImplementedError("kit auto-detection in batch mode is not available on the "
-                                  "MI355X path yet (SURVEY.md 8f rank 1)")
+        if not self.layouts:
+            raise IndexError("list index out of range")
+        if len(set(l.kit for l in self.layouts)) == 1:
+            return self.layouts[0].kit, []          # one kit selected: every read can only vote for it
+        kit = self._native_kit(self.layouts, qcat_config, native.ENDS_BOTH)
+        bases, offsets = native.pack_reads(read_sequences)
+        votes, first = self._context().detect_kit(kit, bases, offsets)
+        counts, seen = {}, {}
+        for t, lay in enumerate(self.layouts):
+            if votes[t]:
+                counts[lay.kit] = counts.get(lay.kit, 0) + int(votes[t])
+                seen[lay.kit] = min(seen.get(lay.kit, len(read_sequences)), int(first[t]))
+        if not counts:
+            return None, []
+        # sorted(..., reverse=True) is stable: equal counts keep dict insertion (= first vote) order
+        best = sorted(counts, key=lambda kname: (-counts[kname], seen[kname]))[0]
+        return best, []
 
     @staticmethod
     def update_barcode_count(result, barcode_count):

@@ -138,3 +138,72 @@ def test_scanner_api_returns_reference_shaped_dicts():
     r = dual.detect_barcode(inl["real_double_barcode_read"])
     assert r["barcode"].name == "barcode06/95" and r["barcode"].id == "6/95"
     assert r["barcode_score"] == 84.78260869565217
+
+
+def test_batch_mode_kit_vote_golden():
+    """detect_kit vote + detect_barcode_batch under kit auto (CLI default)."""
+    inl = helpers.inline_reads()
+    five = [inl[n] for n in ("read", "read_bc3_exact", "read_bc3", "real_bc03_porechop", "read_nobc")]
+    g = helpers.golden()
+    for entry in g["batch"]:
+        det = scanner.factory(kit=entry["kit"])
+        kit_name, _ = det.detect_kit(five)
+        assert kit_name == entry["voted_kit"]
+        res = det.detect_barcode_batch(five, [None] * 5)
+        lays = det.get_adapters(kit_name)
+        for got, w in zip(res, entry["results"]):
+            assert (got["barcode"].name if got["barcode"] else None) == w["barcode_name"]
+            assert float(got["barcode_score"]).hex() == w["score_hex"]
+            assert (got["adapter"].kit if got["adapter"] else None) == w["adapter_kit"]
+            assert (got["adapter_end"], got["trim5p"], got["trim3p"], got["exit_status"]) == \
+                   (w["adapter_end"], w["trim5p"], w["trim3p"], w["exit_status"])
+    det = scanner.factory()
+    for fname, entry in g["batch_fastq"].items():
+        seqs = [s for _, s in helpers.fastq_records(fname)]
+        kit_name, _ = det.detect_kit(seqs)
+        assert kit_name == entry["voted_kit"], fname
+        res = det.detect_barcode_batch(seqs, [None] * len(seqs))
+        for got, w in zip(res, entry["results"]):
+            assert (got["barcode"].id if got["barcode"] else None) == w["barcode_id"]
+            assert float(got["barcode_score"]).hex() == w["score_hex"]
+            assert (got["adapter_end"], got["trim5p"], got["trim3p"], got["exit_status"]) == \
+                   (w["adapter_end"], w["trim5p"], w["trim3p"], w["exit_status"])
+
+
+def test_kit_votes_vs_oracle():
+    det = scanner.factory()                       # the 12 auto-detect templates
+    reads = []
+    for t5, t3, seed in ((3, 2, 11), (5, 4, 12), (1, 0, 13), (9, -1, 14), (10, -1, 15)):
+        reads += synth.synth_batch(120, seed, det.layouts, t5, t3, error_rate=0.1)
+    reads += ["", "ACGT", "N" * 300]
+    d = det.descriptor()
+    want_votes, want_pick = oracle_lib.detect_kit_votes(d, reads)
+    kit = native.NativeKit(d)
+    bases, offsets = native.pack_reads(reads)
+    votes, first = ctx().detect_kit(kit, bases, offsets)
+    assert list(votes) == list(want_votes[:len(det.layouts)])
+    for t in range(len(det.layouts)):
+        idx = np.nonzero(want_pick == t)[0]
+        assert first[t] == (idx[0] if len(idx) else len(reads))
+
+
+def test_generic_device_path_matches_packed_path():
+    """QCAT_HIP_FORCE_GENERIC=1 routes a packed-eligible kit through k_scan_generic: both device
+    paths must produce identical records, traces and per-barcode rows."""
+    import os
+    det = scanner.factory(kit="PBK004/LWB001")
+    reads = synth.synth_batch(400, 31337, det.layouts, 1, 0, error_rate=0.1) + ["", "AC", "N" * 77]
+    d = det.descriptor()
+    kit = native.NativeKit(d)
+    bases, offsets = native.pack_reads(reads)
+    a = ctx().scan(kit, bases, offsets, trace=True, rows=True)
+    os.environ["QCAT_HIP_FORCE_GENERIC"] = "1"
+    try:
+        gctx = native.NativeContext(0)
+    finally:
+        del os.environ["QCAT_HIP_FORCE_GENERIC"]
+    b = gctx.scan(kit, bases, offsets, trace=True, rows=True)
+    assert a[0].tobytes() == b[0].tobytes()
+    for name in native.TRACE_DTYPE.names:
+        assert np.array_equal(a[1][name], b[1][name]), name
+    assert np.array_equal(a[2], b[2])
