@@ -161,11 +161,20 @@ def main():
         value = world * a.reads * a.steps / elapsed
         avg = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
         dom = max(avg, key=avg.get) if avg else None
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                tj = json.load(fh).get(a.workload)
+            if tj and dom and tj["kernel"] == dom:
+                traffic = int(tj["bytes"] * (a.reads / float(tj["reads_per_launch"])))
+        except (IOError, ValueError, KeyError):
+            traffic = None
         roof = None
         if dom:
             achieved = a.reads * bytes_per_read / (avg[dom] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                    "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, scaled to this launch size)" if traffic else None,
                     "algorithmic_bytes_per_launch": a.reads * bytes_per_read,
                     "avg_launch_ms": round(avg[dom], 4),
                     "kernels_avg_ms": {k: round(v, 4) for k, v in avg.items()},

@@ -1,0 +1,138 @@
+"""Full BASELINE sizes on the GPU, checked through size-independent properties:
+  * the count vector equals the histogram recomputed from the records (checksum of checksums)
+    and sums to the number of reads;
+  * idempotence: a second scan of the resident batch returns byte-identical records;
+  * shard invariance: a contiguous slice scanned as its own batch equals the slice of the
+    full-batch records (what multi-GPU sharding relies on);
+  * a random sample of reads, regenerated with the host twin of the generator, goes through the
+    CPU oracle and must match record for record;
+  * error-free synthetic reads are assigned the barcode they were built from.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+from qcat_amd import native, scanner
+
+pytestmark = pytest.mark.gpu
+
+
+class Resident(object):
+    def __init__(self, det, ends, n, seed, e, t5=1, t3=0):
+        self.det, self.n = det, n
+        self.desc = det.descriptor(ends=ends)
+        self.hip = native.HipLibrary.get()
+        self.lib = self.hip.lib
+        self.kit = native.NativeKit(self.desc)
+        self.ctx = native.NativeContext(0)
+        self.sp = native.SynthParams(seed=seed, n_reads=n, insert_len=600, lead_min=5, lead_max=40,
+                                     error_rate=e, no_adapter_fraction=0.05, tpl_5p=t5, tpl_3p=t3)
+        self.batch = C.c_void_p()
+        self.hip.check(self.lib.qcat_batch_synthesize(self.ctx.handle, self.kit.handle, C.byref(self.sp), C.byref(self.batch)))
+
+    def scan(self):
+        self.hip.check(self.lib.qcat_scan_resident(self.ctx.handle, self.kit.handle, self.batch))
+        recs = np.zeros(self.n, dtype=native.RESULT_DTYPE)
+        self.hip.check(self.lib.qcat_ctx_fetch_results(self.ctx.handle, recs.ctypes.data, self.n))
+        cnt = np.zeros(self.desc.n_count_buckets, dtype=np.int64)
+        self.hip.check(self.lib.qcat_ctx_fetch_counts(self.ctx.handle, cnt.ctypes.data, len(cnt)))
+        return recs, cnt
+
+    def host_reads(self, indices):
+        buf = np.zeros(4096, dtype=np.uint8)
+        out = []
+        for i in indices:
+            ln = self.lib.qcat_synth_read(self.kit.handle, C.byref(self.sp), int(i), buf.ctypes.data, buf.size)
+            out.append(buf[:ln].tobytes().decode())
+        return out
+
+    def close(self):
+        self.lib.qcat_batch_destroy(self.batch)
+
+
+def histogram_from_records(desc, layouts, recs):
+    nb, nk = len(desc.slot_ids), len(desc.kit_names)
+    cnt = np.zeros(desc.n_count_buckets, dtype=np.int64)
+    slot_tables = [np.array([desc.id_slots[b.id] for b in lay.barcode_set_1]) for lay in layouts]
+    kit_slot = np.array([desc.kit_slots[lay.kit] for lay in layouts])
+    has = recs["barcode_idx"] >= 0
+    slots = np.full(len(recs), nb, dtype=np.int64)
+    for t in range(len(layouts)):
+        m = has & (recs["adapter_idx"] == t)
+        slots[m] = slot_tables[t][recs["barcode_idx"][m]]
+    cnt[:nb + 1] = np.bincount(slots, minlength=nb + 1)
+    ks = np.where(recs["adapter_idx"] >= 0, kit_slot[np.maximum(recs["adapter_idx"], 0)], nk)
+    cnt[nb + 1:] = np.bincount(ks, minlength=nk + 1)
+    return cnt
+
+
+def check_sample_against_oracle(r, recs, k, rng):
+    idx = np.sort(rng.choice(r.n, size=k, replace=False))
+    want = oracle_lib.scan(r.desc, r.host_reads(idx), threads=8)
+    assert recs[idx].tobytes() == want.tobytes()
+
+
+def test_config2_one_million_reads_5p_only():
+    det = scanner.factory(kit="NBD103/NBD104")
+    r = Resident(det, native.ENDS_5P, 1000000, 20260929, 0.08)
+    try:
+        recs, cnt = r.scan()
+        assert cnt[:13].sum() == r.n and cnt[13:].sum() == r.n
+        assert np.array_equal(cnt, histogram_from_records(r.desc, det.layouts, recs))
+        recs2, cnt2 = r.scan()
+        assert recs2.tobytes() == recs.tobytes() and np.array_equal(cnt, cnt2)          # idempotence
+        check_sample_against_oracle(r, recs, 3000, np.random.default_rng(1))
+        # shard invariance: reads [300000, 300000 + 50000) as their own batch
+        nb = C.c_uint64(); nr = C.c_uint32()
+        r.hip.check(r.lib.qcat_batch_info(r.batch, C.byref(nr), C.byref(nb)))
+        bases = np.zeros(nb.value, dtype=np.uint8); offs = np.zeros(r.n + 1, dtype=np.uint64)
+        r.hip.check(r.lib.qcat_batch_download(r.ctx.handle, r.batch, bases.ctypes.data, offs.ctypes.data))
+        a, b = 300000, 350000
+        sub_b = np.ascontiguousarray(bases[int(offs[a]):int(offs[b])])
+        sub_o = np.ascontiguousarray(offs[a:b + 1] - offs[a])
+        sub = r.ctx.scan(r.kit, sub_b, sub_o)
+        assert sub.tobytes() == recs[a:b].tobytes()
+    finally:
+        r.close()
+
+
+def test_config3_ten_million_reads_both_ends():
+    det = scanner.factory(kit="PBC096")
+    r = Resident(det, native.ENDS_BOTH, 10000000, 20260930, 0.08)
+    try:
+        recs, cnt = r.scan()
+        assert cnt[:97].sum() == r.n
+        assert np.array_equal(cnt, histogram_from_records(r.desc, det.layouts, recs))
+        check_sample_against_oracle(r, recs, 1500, np.random.default_rng(2))
+        # trims are always ordered and inside the read (qcat/test/test_barcode.py:599-603 style)
+        assert (recs["trim5p"] <= recs["trim3p"]).all() and (recs["trim5p"] >= 0).all()
+        called = recs["barcode_idx"] >= 0
+        assert 0.80 < called.mean() < 0.96             # 5 % adapter-free reads, 8 % errors
+        assert set(np.unique(recs["exit_status"])) <= {0, 1, 1002}
+    finally:
+        r.close()
+
+
+def test_error_free_reads_recover_their_barcode():
+    det = scanner.factory(kit="PBC096")
+    n = 200000
+    r = Resident(det, native.ENDS_BOTH, n, 424242, 0.0)
+    try:
+        recs, cnt = r.scan()
+        idx = np.arange(0, n, 97)
+        thr_none = synth.rate_threshold(0.05)
+        for i in idx:
+            rng = synth.SplitMix64(424242, int(i))
+            bare = rng.u24() < thr_none
+            rng.below(36); rng.below(36)
+            b = rng.below(1 << 16) % 96
+            if bare:
+                assert recs[i]["barcode_idx"] == -1 or recs[i]["raw_score"] * 100.0 / recs[i]["score_den"] < 100.0
+            else:
+                assert recs[i]["barcode_idx"] == b and recs[i]["exit_status"] == 0
+                assert recs[i]["raw_score"] == recs[i]["score_den"]        # perfect score 100.0
+    finally:
+        r.close()
