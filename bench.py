@@ -213,7 +213,10 @@ def main():
         # ---- CPU baseline + parity on a bounded sample of rank 0's shard ---------------------
         if not a.no_cpu_baseline:
             import oracle_lib
-            ncpu = os.cpu_count() or 1
+            try:
+                ncpu = len(os.sched_getaffinity(0))          # cores this process may actually use
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
 
             def sample_reads(n):
                 buf = np.zeros(4096, dtype=np.uint8)
@@ -229,8 +232,13 @@ def main():
             t1 = time.perf_counter()
             o1, tr1 = oracle_lib.scan(desc, packed=packed, trace=True, threads=1)
             one_thread = probe / (time.perf_counter() - t1)
-            n_sample = int(min(a.reads, max(probe, one_thread * ncpu * a.cpu_seconds * 0.6)))
-            n_sample = min(n_sample, 400000)
+            # calibrate the all-core rate on a short run, then size the timed sample for ~cpu_seconds
+            probe2 = int(min(a.reads, max(probe, one_thread * min(ncpu, 16) * 1.0)))
+            packed = sample_reads(probe2)
+            t1 = time.perf_counter()
+            oracle_lib.scan(desc, packed=packed, threads=ncpu)
+            rate_all = probe2 / (time.perf_counter() - t1)
+            n_sample = int(min(a.reads, max(probe2, rate_all * a.cpu_seconds)))
             packed = sample_reads(n_sample)
             t1 = time.perf_counter()
             o = oracle_lib.scan(desc, packed=packed, threads=ncpu)

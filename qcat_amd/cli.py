@@ -1,0 +1,286 @@
+"""Command-line driver around the MI355X scanners (the callers and data
+formats either side of the hot path).
+
+Same options, batching and output formats as the reference driver (``qcat/cli.py``): FASTA/FASTQ in
+(``iter_fastx :235-306``, header split ``:200-214``), batches of 4000 reads with a per-batch kit
+vote (``:500-513``), optional trimming (``:521-526``), the minimum-length filter (``:528-530``),
+TSV rows (``:408-442``, header ``:486-487``), per-barcode FASTA/FASTQ files or one annotated stream
+(``:309-358``) and the end-of-run histogram (``:386-405``).  Written from the behaviour, not the
+text, of that file; all alignment work happens in one native call per batch.
+
+    python -m qcat_amd.cli -f reads.fastq -b out_dir --trim
+    python -m qcat_amd.cli -f reads.fastq --tsv -k PBC096 > calls.tsv
+"""
+from __future__ import print_function
+
+import argparse
+import logging
+import os
+import sys
+import time
+
+from . import __version__, config
+from .scanner import factory, get_kits_info, get_modes
+
+BATCH_SIZE = 4000
+
+
+def get_mode(args):
+    if args.MODE_GUPPY:
+        logging.warning("Guppy/pyguppy is not available; using the epi2me scan on the GPU.")
+        return "epi2me"
+    if args.MODE_DUAL:
+        return "dual"
+    if args.MODE_SIMPLE:
+        raise ValueError("simple mode is outside the MI355X hot path (testing/debug mode of the reference)")
+    return "epi2me"
+
+
+def parse_args(argv):
+    p = argparse.ArgumentParser(prog="qcat-mi355x",
+                                description="Demultiplex Oxford Nanopore reads from FASTQ files on an MI355X.")
+    p.add_argument("-V", "--version", action="version", version="%(prog)s " + __version__)
+    p.add_argument("-l", "--log", dest="log", type=str, default="INFO", help="Print debug information")
+    p.add_argument("--quiet", dest="QUIET", action="store_true", help="Don't print summary")
+    g = p.add_argument_group("General settings")
+    g.add_argument("-f", "--fastq", type=str, dest="fastq", help="Barcoded read file")
+    g.add_argument("-b", "--barcode_dir", dest="barcode_dir", type=str, default=None,
+                   help="If specified, qcat will demultiplex reads to this folder")
+    g.add_argument("-o", "--output", dest="output", type=str, default=None,
+                   help="Output file trimmed reads will be written to (default: stdout).")
+    g.add_argument("--min-score", dest="min_qual", type=check_minqual_arg, default=None,
+                   help="Minimum barcode score. Barcode calls with a lower score will be discarded.")
+    g.add_argument("--detect-middle", dest="DETECT_MIDDLE", action="store_true",
+                   help="Search for adapters in the whole read")
+    g.add_argument("-t", "--threads", dest="threads", type=int, default=1, help="Ignored (the scan runs on the GPU)")
+    g.add_argument("--min-read-length", dest="min_length", type=int, default=100,
+                   help="Reads short than <min-read-length> after trimming will be discarded.")
+    g.add_argument("--tsv", dest="tsv", action="store_true", help="Prints a tsv file containing barcode information "
+                                                                 "each read to stdout.")
+    g.add_argument("--trim", dest="TRIM", action="store_true", help="Remove adapter and barcode sequences from reads.")
+    g.add_argument("-k", "--kit", dest="kit", type=str, default="auto",
+                   help="Sequencing kit. Specifying the correct kit will improve sensitivity and specificity "
+                        "and runtime (default: auto)")
+    g.add_argument("--list-kits", dest="list_kits", action="store_true", help="List all supported kits")
+    m = p.add_argument_group("Demultiplexing modes").add_mutually_exclusive_group()
+    m.add_argument("--guppy", dest="MODE_GUPPY", action="store_true")
+    m.add_argument("--epi2me", dest="MODE_EPI2ME", action="store_true", help="Use EPI2ME's demultiplexing algorithm (default)")
+    m.add_argument("--dual", dest="MODE_DUAL", action="store_true", help="Use dual barcoding algorithm")
+    m.add_argument("--simple", dest="MODE_SIMPLE", action="store_true")
+    e = p.add_argument_group("EPI2ME options (only valid with --epi2me)")
+    e.add_argument("--no-batch", dest="nobatch", action="store_true", help="Don't use information from multiple reads for kit detection")
+    e.add_argument("--filter-barcodes", dest="FILTER_BARCODES", action="store_true",
+                   help="Filter rare barcode calls when run in batch mode")
+    p.add_argument("--device", dest="device", type=int, default=0, help="GPU index")
+    return p.parse_args(argv)
+
+
+def check_minqual_arg(x):
+    if x is None:
+        return x
+    x = float(x)
+    if x < 0.0 or x > 100.0:
+        raise argparse.ArgumentTypeError("Minimum quality must be between 0 and 100.")
+    return x
+
+
+def split_header(header):
+    """FASTA/Q title -> (name, comment or None); tabs count as blanks."""
+    cols = header.replace("\t", " ").split(" ")
+    return cols[0], (" ".join(cols[1:]) if len(cols) > 1 else None)
+
+
+def is_fastq(filename):
+    if not filename:
+        return True                       # stdin is assumed to be FASTQ
+    with open(filename) as fh:
+        c = fh.read(1)
+    if c == "@":
+        return True
+    if c == ">":
+        return False
+    raise ValueError("Invalid input file. File must start with '@' or '>'. Current file starts with: " + c)
+
+
+def _fastq_records(handle):
+    """4-line FASTQ records -> (title, seq, qual).  (The reference delegates to Biopython's
+    FastqGeneralIterator, which also accepts wrapped records; ONT FASTQ is 4-line.)"""
+    while True:
+        head = handle.readline()
+        if not head:
+            return
+        if not head.startswith("@"):
+            raise ValueError("Records in Fastq files should start with '@' character")
+        seq = handle.readline().rstrip("\n")
+        plus = handle.readline()
+        qual = handle.readline().rstrip("\n")
+        if not plus.startswith("+") or len(qual) != len(seq):
+            raise ValueError("Malformed FASTQ record: " + head.strip())
+        yield head[1:].rstrip("\n"), seq, qual
+
+
+def _fasta_records(handle):
+    title, chunks = None, []
+    for line in handle:
+        if line.startswith(">"):
+            if title is not None:
+                yield title, "".join(chunks)
+            title, chunks = line[1:].rstrip("\n"), []
+        elif title is not None:
+            chunks.append(line.strip())
+    if title is not None:
+        yield title, "".join(chunks)
+
+
+def iter_fastx(reads_fx, fastq, batchsize):
+    """Yield (names, comments, seqs, quals) lists of at most ``batchsize`` reads."""
+    names, comments, seqs, quals = [], [], [], []
+    handle = open(reads_fx) if reads_fx else sys.stdin
+    try:
+        records = _fastq_records(handle) if fastq else ((t, s, None) for t, s in _fasta_records(handle))
+        for title, seq, qual in records:
+            name, comment = split_header(title)
+            names.append(name)
+            comments.append(comment)
+            seqs.append(seq)
+            quals.append(qual)
+            if len(names) >= batchsize:
+                yield names, comments, seqs, quals
+                names, comments, seqs, quals = [], [], [], []
+    finally:
+        if reads_fx:
+            handle.close()
+    if names:
+        yield names, comments, seqs, quals
+
+
+class _Outputs(object):
+    """Per-barcode files (``-b``) or one annotated stream (``-o`` / stdout)."""
+
+    def __init__(self, out_folder, stream, fastq):
+        self.folder, self.stream, self.fastq, self.files = out_folder, stream, fastq, {}
+        if out_folder and not os.path.exists(out_folder):
+            os.makedirs(out_folder)
+
+    def write(self, name, comment, sequence, quality, result):
+        comment = comment or ""
+        quality = quality or ""
+        if self.folder:
+            key = "none"
+            if result["barcode"]:
+                key = result["barcode"].name
+                if key:
+                    key = key.replace("/", "_")
+            fh = self.files.get(key)
+            if fh is None:
+                fh = self.files[key] = open(os.path.join(self.folder, key + (".fastq" if self.fastq else ".fasta")), "w")
+        else:
+            fh = self.stream
+            comment = "{} barcode={}".format(comment, str(result["barcode"].id) if result["barcode"] else "none")
+        if self.fastq:
+            fh.write("@" + name + " " + comment + "\n" + sequence + "\n+\n" + quality + "\n")
+        else:
+            fh.write(">" + name + " " + comment + "\n" + sequence + "\n")
+
+    def close(self):
+        for fh in self.files.values():
+            fh.close()
+
+
+def tsv_row(result, comment, name, sequence):
+    if result["barcode"]:
+        kit_name = result["adapter"].kit if result["adapter"] else None
+        cols = (name, len(sequence), result["barcode"].id, result["barcode_score"], kit_name, result["adapter_end"], comment)
+    else:
+        cols = (name, len(sequence), "none", "-1", "none", "-1", comment)
+    return "\t".join(str(c) for c in cols)
+
+
+def histogram_lines(barcode_dist, adapter_dist, total_reads):
+    lines = ["Adapters detected in %d of %d reads" % (sum(v for k, v in adapter_dist.items() if k != "none"), total_reads)]
+    for key in sorted(adapter_dist):
+        perc = adapter_dist[key] * 100.0 / total_reads
+        lines.append("%15s %6d: | %20s | %6s %%" % (key, adapter_dist[key], int(perc / 5) * "#", "{:.2f}".format(perc)))
+    lines.append("Barcodes detected in %d of %d adapters" % (sum(v for k, v in barcode_dist.items() if k != "none"), total_reads))
+    for key in sorted(barcode_dist):
+        perc = barcode_dist[key] * 100.0 / total_reads
+        lines.append("%15s %6d: | %20s | %6s %%" % (key, barcode_dist[key], int(perc / 5) * "#", "{:.2f}".format(perc)))
+    return lines
+
+
+def qcat_cli(reads_fq, kit, mode, nobatch, out, min_qual, tsv, output, threads, trim, adapter_yaml, quiet,
+             filter_barcodes, middle_adapter, min_read_length, qcat_config, device=0, tsv_stream=None):
+    """Demultiplex one FASTA/FASTQ file; returns (barcode_dist, adapter_dist, total, skipped)."""
+    tsv_stream = tsv_stream or sys.stdout
+    detector = factory(mode=mode, kit=kit, min_quality=min_qual, kit_folder=adapter_yaml,
+                       enable_filter_barcodes=filter_barcodes, scan_middle_adapter=middle_adapter,
+                       threads=threads, device=device)
+    if tsv:
+        print("name", "length", "barcode", "score", "kit", "adapter_end", "comment", sep="\t", file=tsv_stream)
+    fastq = is_fastq(reads_fq)
+    stream = open(output, "w") if output else sys.stdout
+    outputs = _Outputs(out, stream, fastq)
+    barcode_dist, adapter_dist, total_reads, skipped_reads = {}, {}, 0, 0
+    for names, comments, seqs, quals in iter_fastx(reads_fq, fastq, 1 if nobatch else BATCH_SIZE):
+        if nobatch:
+            results = [detector.detect_barcode(read_sequence=seqs[0], read_qualities=quals[0], qcat_config=qcat_config)]
+        else:
+            results = detector.detect_barcode_batch(read_sequences=seqs, read_qualities=quals, qcat_config=qcat_config)
+        for name, comment, sequence, quality, result in zip(names, comments, seqs, quals, results):
+            total_reads += 1
+            if trim:
+                sequence = sequence[result["trim5p"]:result["trim3p"]]
+                if quality:
+                    quality = quality[result["trim5p"]:result["trim3p"]]
+            if len(sequence) < min_read_length:
+                skipped_reads += 1
+                continue
+            bkey = result["barcode"].name if result["barcode"] else "none"
+            akey = result["adapter"].kit if result["adapter"] else "none"
+            barcode_dist[bkey] = barcode_dist.get(bkey, 0) + 1
+            adapter_dist[akey] = adapter_dist.get(akey, 0) + 1
+            if tsv:
+                print(tsv_row(result, comment, name, sequence), file=tsv_stream)
+            if out or not tsv:
+                outputs.write(name, comment, sequence, quality, result)
+    outputs.close()
+    if not quiet:
+        for line in histogram_lines(barcode_dist, adapter_dist, total_reads):
+            logging.info(line)
+        if skipped_reads > 0:
+            logging.info("{} reads were skipped due to the min. length filter.".format(skipped_reads))
+    if output:
+        stream.close()
+    return barcode_dist, adapter_dist, total_reads, skipped_reads
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    try:
+        args = parse_args(argv)
+        level = getattr(logging, args.log.upper(), None)
+        if not isinstance(level, int):
+            raise ValueError("Invalid log level: %s" % args.log.upper())
+        logging.basicConfig(level=level, format="%(message)s")
+        if args.list_kits:
+            kits = get_kits_info()
+            for kit in sorted(kits):
+                if kit != "auto" and kit != "DUAL":
+                    logging.info("{:<30}{}".format(kit, kits[kit]))
+            return
+        start = time.time()
+        qcat_cli(reads_fq=args.fastq, kit=args.kit, mode=get_mode(args), nobatch=args.nobatch, out=args.barcode_dir,
+                 min_qual=args.min_qual, tsv=args.tsv, output=args.output, threads=args.threads, trim=args.TRIM,
+                 adapter_yaml=None, quiet=args.QUIET, filter_barcodes=args.FILTER_BARCODES,
+                 middle_adapter=args.DETECT_MIDDLE, min_read_length=args.min_length,
+                 qcat_config=config.get_default_config(), device=args.device)
+        if not args.QUIET:
+            logging.info("Demultiplexing finished in {0:.2f}s".format(time.time() - start))
+    except IOError as e:
+        logging.error(e)
+    except ValueError as e:
+        logging.error(e)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/cli_golden.json: outputs of the UNMODIFIED reference driver
+(`qcat.cli.qcat_cli`, /root/reference, read-only) over the four shipped FASTQ files, for the
+host-pipeline parity tests.  Dev tool for the authoring container; see
+make_golden.py for what is real (all of qcat's Python) and what is a stand-in (parasail -> oracle
+DP, Bio parsers)."""
+import contextlib
+import hashlib
+import io
+import json
+import logging
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden  # noqa: E402
+
+
+def sha(path):
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
+def main():
+    make_golden.install_standins()
+    make_golden.import_reference()
+    import qcat.cli as ref_cli
+    import qcat.config as ref_config
+
+    class Capture(logging.Handler):
+        def __init__(self):
+            logging.Handler.__init__(self)
+            self.lines = []
+
+        def emit(self, record):
+            self.lines.append(record.getMessage())
+
+    cap = Capture()
+    logging.getLogger().addHandler(cap)
+    logging.getLogger().setLevel(logging.INFO)
+    cfg = ref_config.get_default_config()
+    runs = []
+    data = os.path.join(HERE, "data")
+    variants = [
+        {"tag": "tsv-auto-batch", "kit": "auto", "mode": "epi2me", "nobatch": False, "tsv": True, "trim": False, "min_len": 100, "dir": False},
+        {"tag": "tsv-auto-nobatch-trim", "kit": "auto", "mode": "epi2me", "nobatch": True, "tsv": True, "trim": True, "min_len": 100, "dir": False},
+        {"tag": "dir-auto-trim", "kit": "auto", "mode": "epi2me", "nobatch": False, "tsv": False, "trim": True, "min_len": 100, "dir": True},
+        {"tag": "stream-kit-trim-minlen1000", "kit": None, "mode": "epi2me", "nobatch": False, "tsv": False, "trim": True, "min_len": 1000, "dir": False},
+        {"tag": "tsv-dual", "kit": "auto", "mode": "dual", "nobatch": False, "tsv": True, "trim": False, "min_len": 100, "dir": False},
+    ]
+    file_kits = {"nbd103.fastq": "NBD104/NBD114", "pbk004.fastq": "PBK004/LWB001",
+                 "rab204.fastq": "RAB204/RAB214", "rbk004.fastq": "RBK004"}
+    for fname in sorted(file_kits):
+        for v in variants:
+            kit = v["kit"] if v["kit"] else file_kits[fname]
+            tmp = tempfile.mkdtemp(prefix="qcat_cli_")
+            outdir = os.path.join(tmp, "bc") if v["dir"] else None
+            outfile = os.path.join(tmp, "out.fastq")
+            cap.lines = []
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                ref_cli.qcat_cli(reads_fq=os.path.join(data, fname), kit=kit, mode=v["mode"], nobatch=v["nobatch"],
+                                 out=outdir, min_qual=None, tsv=v["tsv"], output=None if v["dir"] else outfile,
+                                 threads=1, trim=v["trim"], adapter_yaml=None, quiet=False, filter_barcodes=False,
+                                 middle_adapter=False, min_read_length=v["min_len"], qcat_config=cfg)
+            files = {}
+            if outdir:
+                for f in sorted(os.listdir(outdir)):
+                    files[f] = sha(os.path.join(outdir, f))
+            elif os.path.exists(outfile):
+                files["out.fastq"] = sha(outfile)
+            runs.append({"file": fname, "variant": v, "kit": kit, "stdout": buf.getvalue(),
+                         "log": list(cap.lines), "files": files})
+            print(fname, v["tag"], len(buf.getvalue()), "bytes stdout,", len(files), "files")
+    with open(os.path.join(HERE, "cli_golden.json"), "w") as fh:
+        json.dump({"generator": "tests/golden/make_cli_golden.py", "runs": runs}, fh, separators=(",", ":"))
+    print("cli_golden.json", os.path.getsize(os.path.join(HERE, "cli_golden.json")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+"""Host pipeline parity: qcat_amd.cli.qcat_cli against the outputs of the
+reference driver on the four shipped FASTQ files (tests/golden/cli_golden.json, made by
+tests/golden/make_cli_golden.py): TSV text, per-barcode / annotated FASTQ files (sha256), and the
+end-of-run histogram lines."""
+import hashlib
+import io
+import json
+import logging
+import os
+
+import pytest
+
+import helpers
+from qcat_amd import cli, config
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(helpers.GOLDEN, "cli_golden.json")) as _fh:
+    RUNS = json.load(_fh)["runs"]
+
+
+class _Capture(logging.Handler):
+    def __init__(self):
+        logging.Handler.__init__(self)
+        self.lines = []
+
+    def emit(self, record):
+        self.lines.append(record.getMessage())
+
+
+def _sha(path):
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
+@pytest.mark.parametrize("idx", range(len(RUNS)), ids=["%s:%s" % (r["file"], r["variant"]["tag"]) for r in RUNS])
+def test_cli_matches_reference_driver(idx, tmp_path):
+    run = RUNS[idx]
+    v = run["variant"]
+    outdir = str(tmp_path / "bc") if v["dir"] else None
+    outfile = str(tmp_path / "out.fastq")
+    cap = _Capture()
+    root = logging.getLogger()
+    old_level = root.level
+    root.addHandler(cap)
+    root.setLevel(logging.INFO)
+    buf = io.StringIO()
+    try:
+        cli.qcat_cli(reads_fq=os.path.join(helpers.GOLDEN, "data", run["file"]), kit=run["kit"], mode=v["mode"],
+                     nobatch=v["nobatch"], out=outdir, min_qual=None, tsv=v["tsv"],
+                     output=None if v["dir"] else outfile, threads=1, trim=v["trim"], adapter_yaml=None,
+                     quiet=False, filter_barcodes=False, middle_adapter=False, min_read_length=v["min_len"],
+                     qcat_config=config.get_default_config(), tsv_stream=buf)
+    finally:
+        root.removeHandler(cap)
+        root.setLevel(old_level)
+    assert buf.getvalue() == run["stdout"]
+    assert cap.lines == run["log"]
+    files = {}
+    if outdir:
+        for f in sorted(os.listdir(outdir)):
+            files[f] = _sha(os.path.join(outdir, f))
+    elif os.path.exists(outfile):
+        files["out.fastq"] = _sha(outfile)
+    assert files == run["files"]
