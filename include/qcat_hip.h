@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QCAT_ABI_VERSION 1
+#define QCAT_ABI_VERSION 2
 
 /* Base code space shared by host and device (qcat_amd/codes.py): parasail's mapper sends the
  * alphabet letters (either case) to their index and everything else to the '*' row
@@ -108,6 +108,11 @@ typedef struct qcat_kit_desc {
     double  region_min_adapter_score;/* 90.0 (scanner_epi2me.py:74)                           */
     int32_t n_barcode_slots;         /* number of distinct ids over all sets (count buckets)  */
     int32_t n_kit_slots;             /* number of distinct kit names                          */
+    /* --detect-middle (qcat/scanner_base.py:479-519, :593-595): after the two end scans, the read
+     * interior read[n:-n] and its reverse complement are scanned with the templates of the called
+     * kit; a barcode score >= middle_min_score (50.0) there voids the call (exit_status 997). */
+    int32_t scan_middle_adapter;
+    double  middle_min_score;
 } qcat_kit_desc;
 
 /* Result record: the dict of qcat/scanner_base.py:381-388 as indices (24 bytes, little endian).
@@ -117,7 +122,7 @@ typedef struct qcat_result {
     int16_t barcode_idx;    /* index into templates[adapter_idx].sets[0]; -1 = None            */
     int16_t barcode2_idx;   /* dual mode: index into sets[1]; -1 otherwise                     */
     int16_t adapter_idx;    /* template index; -1 = None                                       */
-    int16_t exit_status;    /* 0 / 1 / 1002 (/ 997 once scan_middle exists)                    */
+    int16_t exit_status;    /* 0 / 1 / 1002 (ends disagree) / 997 (adapter in the read interior) */
     int32_t adapter_end;
     int32_t trim5p;
     int32_t trim3p;

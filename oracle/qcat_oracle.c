@@ -37,7 +37,7 @@
 #include "../include/qcat_hip.h"
 
 #define QO_NEG (-(1 << 28))
-#define QO_MAXW 4096            /* longest query the oracle accepts (windows are <= 160) */
+#define QO_MAXW (1 << 26)       /* longest query qo_sg accepts */
 
 static __thread char qo_err[256];
 const char* qo_last_error(void) { return qo_err; }
@@ -71,7 +71,7 @@ typedef struct qo_align { int32_t score, end_query, end_ref; } qo_align;
 void qo_sg_codes(const uint8_t* q, int L, const uint8_t* t, int M, int open, int extend,
                  const int8_t* mat, qo_align* out) {
     int32_t Hrow[QCAT_MAX_TEMPLATE_LEN + 2], Frow[QCAT_MAX_TEMPLATE_LEN + 2];
-    int32_t lastcol[QO_MAXW + 1];
+    int32_t cmax = QO_NEG, cfirst = 0;      /* last-column maximum and the first row reaching it */
     for (int j = 0; j <= M; ++j) { Hrow[j] = 0; Frow[j] = QO_NEG; }
     for (int i = 1; i <= L; ++i) {
         const int8_t* wrow = mat;           /* indexed [tc*7 + qc] */
@@ -91,18 +91,15 @@ void qo_sg_codes(const uint8_t* q, int L, const uint8_t* t, int M, int open, int
             diag = up;
             Hrow[j] = h; Frow[j] = f; e = ee; hleft = h;
         }
-        lastcol[i] = Hrow[M];
+        if (Hrow[M] > cmax) { cmax = Hrow[M]; cfirst = i; }
     }
     /* end position: parasail sg_striped rule */
     int32_t score = QO_NEG, end_q = L - 1, end_r = 0;
     for (int j = 1; j <= M; ++j) {          /* row "query fully consumed", strict > */
         if (Hrow[j] > score) { score = Hrow[j]; end_r = j - 1; end_q = L - 1; }
     }
-    int32_t cmax = QO_NEG;
-    for (int i = 1; i <= L; ++i) if (lastcol[i] > cmax) cmax = lastcol[i];
     if (cmax > score || (cmax == score && end_r == M - 1)) {
-        score = cmax; end_r = M - 1;
-        for (int i = 1; i <= L; ++i) if (lastcol[i] == cmax) { end_q = i - 1; break; }
+        score = cmax; end_r = M - 1; end_q = cfirst - 1;
     }
     out->score = score; out->end_query = end_q; out->end_ref = end_r;
 }
@@ -369,6 +366,52 @@ static int qo_same_id(const qo_kit* k, const qo_scan* a, const qo_scan* b) {
     return 1;
 }
 
+/* scan_middle, qcat/scanner_base.py:479-519: scan() (epi2me: scanner_epi2me.py:33-144, dual:
+ * scanner_dual.py:35-146) of the read interior read[n:-n] and of its reverse complement with the
+ * templates of one kit (get_adapters, :606-611); True as soon as one strand reaches barcode_score
+ * >= middle_min_score. */
+static double qo_scan_seq_score(const qo_kit* k, const uint8_t* w, int L, int kit_slot) {
+    int sub[QCAT_MAX_TEMPLATES], ns = 0;
+    for (int t = 0; t < k->nt; ++t) if (k->d.templates[t].kit_slot == kit_slot) sub[ns++] = t;
+    qo_best_tpl b = { -1, -1, -1.0, -1 };
+    if (ns > 0 && L > 0) {
+        for (int i = 0; i < ns; ++i) {
+            const qo_tpl* p = &k->tpl[sub[i]];
+            qo_align a;
+            qo_sg_codes(w, L, p->codes, p->len, k->d.gap_open, k->d.gap_extend, k->d.adapter_matrix, &a);
+            double norm = a.score * 100.0 / (double)p->den;
+            if (b.score < norm) { b.score = norm; b.idx = i; b.end = a.end_query; b.raw = a.score; }
+        }
+    }
+    const qo_tpl* p = &k->tpl[sub[b.idx < 0 ? ns + b.idx : b.idx]];
+    const int dual = k->d.mode == QCAT_MODE_DUAL;
+    int start, len, raw0 = 0, raw1 = 0, bc0, bc1 = -1;
+    if (dual || b.score > k->d.region_min_adapter_score || p->is_double) qo_region(k, p, 0, b.end, L, &start, &len);
+    else { start = 0; len = L < k->d.max_align_length ? L : k->d.max_align_length; }
+    bc0 = qo_best_barcode(k, &p->sets[0], w + start, len, &raw0, NULL);
+    if (!dual) return bc0 >= 0 ? raw0 * 100.0 / (1.0 * p->sets[0].tlen) : 0.0;
+    qo_region(k, p, 1, b.end, L, &start, &len);
+    bc1 = qo_best_barcode(k, &p->sets[1], w + start, len, &raw1, NULL);
+    if (bc0 < 0 || bc1 < 0) return 0.0;
+    double s0 = raw0 * 100.0 / (1.0 * p->sets[0].tlen), s1 = raw1 * 100.0 / (1.0 * p->sets[1].tlen);
+    return s1 < s0 ? s1 : s0;
+}
+
+static int qo_scan_middle(const qo_kit* k, const uint8_t* read, int64_t len, int kit_slot) {
+    const int n = k->d.max_align_length;
+    int64_t m = len - 2 * (int64_t)n;                  /* len(sequence[n:-n]) */
+    if (m < 0) m = 0;
+    uint8_t* w = (uint8_t*)malloc((size_t)m + 1);
+    int hit = 0;
+    for (int strand = 0; strand < 2 && !hit; ++strand) {
+        for (int64_t i = 0; i < m; ++i)
+            w[i] = strand == 0 ? qo_code_of[read[n + i]] : qo_code_of[qo_comp_of[read[len - n - 1 - i]]];
+        if (!(qo_scan_seq_score(k, w, (int)m, kit_slot) < k->d.middle_min_score)) hit = 1;
+    }
+    free(w);
+    return hit;
+}
+
 static void qo_to_record(const qo_scan* s, int trim5, int64_t trim3, qcat_result* o) {
     o->barcode_idx = (int16_t)s->bc[0]; o->barcode2_idx = (int16_t)s->bc[1];
     o->adapter_idx = (int16_t)s->adapter; o->exit_status = (int16_t)s->exit_status;
@@ -407,6 +450,10 @@ static void qo_detect_barcode(const qo_kit* k, const uint8_t* read, int64_t len,
             !qo_same_id(k, &r5, &r3)) {
             res = qo_empty(); res.exit_status = 1002;
         }
+    }
+    if (k->d.scan_middle_adapter && res.adapter >= 0 &&
+        qo_scan_middle(k, read, len, k->d.templates[res.adapter].kit_slot)) {
+        res = qo_empty(); res.exit_status = 997;             /* scanner_base.py:593-595 */
     }
     if (trim3 < trim5) trim5 = 0;
     qo_to_record(&res, trim5, trim3, o);

@@ -46,6 +46,7 @@ struct DevSet {
     int32_t width;              // register-array width class of the packed barcode kernel
     int32_t min_raw_pass;       // smallest raw with raw*100.0/tlen >= min_quality
     int32_t min_raw_conflict;   // smallest raw with raw*100.0/tlen >= conflict_min_score
+    int32_t min_raw_middle;     // smallest raw with raw*100.0/tlen >= middle_min_score (--detect-middle)
 };
 
 struct DevTpl {
@@ -62,6 +63,7 @@ struct DevKit {
     int32_t mode, ends, nt;
     int32_t gap_open, gap_extend, max_align, ext;
     int32_t n_barcode_slots, n_kit_slots, n_buckets;
+    int32_t scan_middle;        // --detect-middle enabled
     int32_t fast_ok;            // every template/set is eligible for the packed fast path
     uint32_t special_adapter;   // v_perm pool bytes for query codes N, X, other, PAD (adapter)
     uint32_t special_barcode;   //   "    (barcode alignments)

@@ -275,9 +275,16 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         // every block zeroes and flushes an LDS histogram of n_buckets entries: fewer, fatter blocks
         // when the bucket vector is long (dual kits)
         uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, hk.n_buckets > 2048 ? 512 : 4096);
+        const bool middle = hk.scan_middle != 0;
         hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, c->stream,
-                           kp, c->recs, b->offsets, n, c->results, c->counts);
+                           kp, c->recs, b->offsets, n, c->results, middle ? nullptr : c->counts);
         mark(c, "k_finalize");
+        if (middle) {
+            hipLaunchKernelGGL(k_scan_middle, dim3((n + GEN_THREADS - 1) / GEN_THREADS), dim3(GEN_THREADS), 0, c->stream,
+                               kp, b->bases, b->offsets, n, c->results);
+            hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, c->stream, kp, c->results, n, c->counts);
+            mark(c, "k_scan_middle");
+        }
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MODE_EPI2ME, MODE_DUAL = 0, 1
 ENDS_5P, ENDS_BOTH = 1, 3
 MAX_TEMPLATES = 16
@@ -41,7 +41,8 @@ class KitDesc(C.Structure):
                 ("adapter_matrix", C.c_int8 * 49), ("barcode_matrix", C.c_int8 * 49),
                 ("min_quality", C.c_double), ("conflict_min_score", C.c_double),
                 ("region_min_adapter_score", C.c_double),
-                ("n_barcode_slots", C.c_int32), ("n_kit_slots", C.c_int32)]
+                ("n_barcode_slots", C.c_int32), ("n_kit_slots", C.c_int32),
+                ("scan_middle_adapter", C.c_int32), ("middle_min_score", C.c_double)]
 
 
 class Result(C.Structure):
@@ -80,7 +81,8 @@ class KitDescriptor(object):
     equality, qcat/scanner_base.py:589, and used as count keys, :680-689).
     """
 
-    def __init__(self, layouts, qcat_config, mode="epi2me", min_quality=None, ends=ENDS_BOTH):
+    def __init__(self, layouts, qcat_config, mode="epi2me", min_quality=None, ends=ENDS_BOTH,
+                 scan_middle=False):
         if mode not in ("epi2me", "dual"):
             raise RuntimeError("Invalid demultiplexing mode: {}".format(mode))
         if len(layouts) > MAX_TEMPLATES:
@@ -154,6 +156,9 @@ class KitDescriptor(object):
         d.region_min_adapter_score = 90.0
         d.n_barcode_slots = len(self.slot_ids)
         d.n_kit_slots = len(self.kit_names)
+        d.scan_middle_adapter = 1 if scan_middle else 0
+        d.middle_min_score = 50.0
+        self.scan_middle = bool(scan_middle)
         self.desc = d
 
     @property

@@ -76,18 +76,21 @@ class BarcodeScanner(object):
         raise NotImplementedError("Abstract class")
 
     # -- native plumbing ------------------------------------------------------------------------
-    def descriptor(self, layouts=None, qcat_config=None, ends=native.ENDS_BOTH):
+    def descriptor(self, layouts=None, qcat_config=None, ends=native.ENDS_BOTH, scan_middle=None):
         """KitDescriptor for ``layouts`` (default: this scanner's) -- also used by the tests to
         drive the CPU oracle with exactly the product's descriptor."""
         if qcat_config is None:
             qcat_config = config.qcatConfig()
         if layouts is None:
             layouts = self.layouts
+        if scan_middle is None:
+            scan_middle = self.scan_middle_adapter and ends == native.ENDS_BOTH
         return native.KitDescriptor(layouts, qcat_config, mode=self._native_mode,
-                                    min_quality=self.min_quality, ends=ends)
+                                    min_quality=self.min_quality, ends=ends, scan_middle=scan_middle)
 
     def _native_kit(self, layouts, qcat_config, ends):
-        key = (tuple(id(l) for l in layouts), qcat_config.fingerprint(), ends, self.min_quality)
+        key = (tuple(id(l) for l in layouts), qcat_config.fingerprint(), ends, self.min_quality,
+               bool(self.scan_middle_adapter))
         kit = self._kits.get(key)
         if kit is None:
             kit = native.NativeKit(self.descriptor(layouts, qcat_config, ends))
@@ -117,9 +120,6 @@ class BarcodeScanner(object):
                                  trim3p=int(rec["trim3p"]))
 
     def _run(self, read_sequences, layouts, qcat_config, ends=native.ENDS_BOTH):
-        if self.scan_middle_adapter:
-            raise NotImplementedError("scan_middle_adapter (--detect-middle) is not available on "
-                                      "the MI355X path yet (SURVEY.md 8f rank 3)")
         if not layouts:
             # the reference indexes an empty template list here (IndexError)
             raise IndexError("list index out of range")

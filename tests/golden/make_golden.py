@@ -370,12 +370,38 @@ def main():
         tracer.take()
         scan5.append(result_to_json(res, det.layouts))
 
+    # 8. --detect-middle (scan_middle, scanner_base.py:479-519, :593-595): chimeric reads (two
+    #    synthetic reads joined head to tail carry adapters in their interior), short reads, plain reads
+    middle = []
+    for mode, kit in (("epi2me", "PBC096"), ("epi2me", None), ("dual", None)):
+        det = ref_scanner.factory(mode=mode, kit=kit, scan_middle_adapter=True)
+        lays = det.layouts
+        t5, t3 = (3, 2) if kit is None and mode == "epi2me" else (1, 0)
+        gen = {"seed": seed0 + 20, "n": 24, "tpl_5p": t5, "tpl_3p": t3, "error_rate": 0.05}
+        base = synth.synth_batch(48, gen["seed"], lays, t5, t3, error_rate=gen["error_rate"])
+        reads = []
+        for i in range(24):
+            if i % 3 == 0:
+                reads.append(base[i] + base[i + 24])                 # chimera: adapters in the middle
+            elif i % 3 == 1:
+                reads.append(base[i])
+            else:
+                reads.append(base[i][:120 + 17 * i])                 # short reads around 2 x 150
+        recs = []
+        for r in reads:
+            tracer.take()
+            res = det.detect_barcode(r, qcat_config=cfg)
+            tracer.take()
+            recs.append(result_to_json(res, lays))
+        middle.append({"mode": mode, "kit": kit, "gen": gen, "results": recs})
+        print("middle %s/%s: exit codes %s" % (mode, kit, sorted(set(x["exit_status"] for x in recs))))
+
     with open(os.path.join(HERE, "golden_vectors.json"), "w") as fh:
         json.dump({"generator": "tests/golden/make_golden.py",
                    "template_order": "sorted by kit file name",
                    "dp": "oracle restatement (parasail absent) -- see make_golden.py docstring",
                    "cases": cases, "region_table": region_table, "batch": batch,
-                   "batch_fastq": per_file_votes,
+                   "batch_fastq": per_file_votes, "middle": middle,
                    "scan5p": {"kit": "NBD103/NBD104",
                               "gen": {"seed": seed0 + 12, "n": 48, "tpl_5p": 1, "tpl_3p": 0, "error_rate": 0.08,
                                       "no_adapter_fraction": 0.05, "insert_len": 600, "lead_min": 5, "lead_max": 40},

@@ -102,3 +102,18 @@ def assert_case_matches(case, recs, traces, rows, layouts):
                     if mode != "dual" and k == 1:
                         continue
                     assert list(rows[2 * i + e, k, :len(wrow)]) == wrow, (case["name"], i, e, k)
+
+
+def middle_reads(entry, layouts):
+    """Re-create the read list of one `middle` fixture (see make_golden.py section 8)."""
+    g = entry["gen"]
+    base = synth.synth_batch(48, g["seed"], layouts, g["tpl_5p"], g["tpl_3p"], error_rate=g["error_rate"])
+    reads = []
+    for i in range(24):
+        if i % 3 == 0:
+            reads.append(base[i] + base[i + 24])
+        elif i % 3 == 1:
+            reads.append(base[i])
+        else:
+            reads.append(base[i][:120 + 17 * i])
+    return reads

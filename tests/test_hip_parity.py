@@ -207,3 +207,34 @@ def test_generic_device_path_matches_packed_path():
     for name in native.TRACE_DTYPE.names:
         assert np.array_equal(a[1][name], b[1][name]), name
     assert np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("i", range(3))
+def test_detect_middle_golden_and_oracle(i):
+    """--detect-middle: exit_status 997 etc. against the reference fixtures, and a
+    larger chimeric batch against the oracle."""
+    entry = helpers.golden()["middle"][i]
+    det = scanner.factory(mode=entry["mode"], kit=entry["kit"], scan_middle_adapter=True)
+    reads = helpers.middle_reads(entry, det.layouts)
+    d = det.descriptor()
+    kit = native.NativeKit(d)
+    bases, offsets = native.pack_reads(reads)
+    cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+    recs = ctx().scan(kit, bases, offsets, counts=cnt)
+    for rec, want in zip(recs, entry["results"]):
+        assert helpers.record_as_golden(rec, det.layouts, entry["mode"]) == want
+    # dict-level API
+    res = det.detect_barcode_batch(reads, [None] * len(reads)) if entry["kit"] else [det.detect_barcode(r) for r in reads]
+    assert [r["exit_status"] for r in res] == [w["exit_status"] for w in entry["results"]]
+    # bigger batch vs oracle (records + counts)
+    g = entry["gen"]
+    base = synth.synth_batch(300, 777 + i, det.layouts, g["tpl_5p"], g["tpl_3p"], error_rate=0.08)
+    # a read joined to itself keeps one barcode at both ends (no 1002) and has adapters inside
+    big = [base[j] + base[j] if j % 2 else base[j] for j in range(150)] + ["", "ACGT" * 80, "N" * 700]
+    bases, offsets = native.pack_reads(big)
+    cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+    recs = ctx().scan(kit, bases, offsets, counts=cnt)
+    o_recs, o_cnt = oracle_lib.scan(d, big, counts=True, threads=8)
+    assert recs.tobytes() == o_recs.tobytes()
+    assert np.array_equal(cnt, o_cnt)
+    assert (recs["exit_status"] == 997).sum() > 10

@@ -58,3 +58,16 @@ def test_batch_fixed_kit_matches_per_read():
     recs = oracle_lib.scan(det.descriptor(), five)
     for rec, want in zip(recs, entry["results"]):
         assert helpers.record_as_golden(rec, det.layouts, "epi2me") == want
+
+
+@pytest.mark.parametrize("i", range(3))
+def test_detect_middle(i):
+    """--detect-middle (scan_middle, qcat/scanner_base.py:479-519): exit_status 997 and the rest of
+    the dict against the reference."""
+    entry = helpers.golden()["middle"][i]
+    det = scanner.factory(mode=entry["mode"], kit=entry["kit"], scan_middle_adapter=True)
+    reads = helpers.middle_reads(entry, det.layouts)
+    recs = oracle_lib.scan(det.descriptor(), reads)
+    assert 997 in [int(r["exit_status"]) for r in recs]
+    for rec, want in zip(recs, entry["results"]):
+        assert helpers.record_as_golden(rec, det.layouts, entry["mode"]) == want
