@@ -33,7 +33,7 @@ inline int adapter_width_class(int len) {
     return 0;
 }
 inline int barcode_width_class(int len) {
-    const int w[] = {40, 44, 48, 56, 64};
+    const int w[] = {40, 42, 44, 46, 48, 56, 64};
     for (int v : w) if (len <= v && v - len <= PADMAX) return v;
     return 0;
 }
