@@ -52,7 +52,7 @@ extern "C" int qcat_device_count(void) {
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_DEVICES = 16;
 
-struct DevSynthTpl { qsynth::Tpl t; };
+
 
 struct KitOnDevice {
     bool ready = false;
