@@ -1,0 +1,58 @@
+// mix_rate.hip -- what does one DP column cost?  Compares the two candidate instruction mixes for the
+// score lookup of the packed kernels at 4 waves/SIMD:
+//   A: v_perm_b32 + v_add_u32 + 2 x v_pk_max_u16                (all VALU)
+//   B: ds_bpermute_b32 (LDS crossbar) + v_add_u32 + 2 x v_pk_max_u16
+// Each "column" keeps the real dependency shape: w -> d = diag + w -> m = max(d, up) -> left = max(m, left).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define NCOL 44
+#define ROWS 2048
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ inline us2 U(unsigned x) { return __builtin_bit_cast(us2, x); }
+__device__ inline unsigned X(us2 x) { return __builtin_bit_cast(unsigned, x); }
+
+template <int MODE>
+__global__ void __launch_bounds__(64, 4) k(unsigned* out, const unsigned* in, unsigned seed) {
+    unsigned tbl[NCOL]; us2 h[NCOL + 1];
+    for (int j = 0; j < NCOL; ++j) { tbl[j] = in[(j * 64 + threadIdx.x) & 1023] | 0x00010001u; asm volatile("" : "+v"(tbl[j])); h[j] = U(j * 0x00010001u); }
+    h[NCOL] = U(0);
+    unsigned special = seed * 3 + 1;
+    asm volatile("" : "+v"(special));
+    for (int i = 0; i < ROWS; ++i) {
+        unsigned q = (in[(i + threadIdx.x) & 1023] + i);
+        unsigned sel = (q & 0x00030003u) | 0x0C000C00u;
+        int addr = (int)((q & 63u) << 2);
+        us2 left = U(i * 0x00010001u), carry = left;
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) {
+            unsigned w;
+            if (MODE == 0) w = __builtin_amdgcn_perm(special, tbl[j], sel);
+            else w = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)tbl[j]);
+            us2 up = h[j + 1];
+            us2 d = U(X(carry) + w);
+            carry = up;
+            left = __builtin_elementwise_max(__builtin_elementwise_max(d, up), left);
+            h[j + 1] = left;
+        }
+    }
+    unsigned acc = 0;
+    for (int j = 0; j <= NCOL; ++j) acc += X(h[j]);
+    out[blockIdx.x * 64 + threadIdx.x] = acc;
+}
+
+template <int MODE> void run(const char* name, unsigned* d, unsigned* in) {
+    const int blocks = 256 * 16;        // 16 one-wave blocks per CU = 4 waves per SIMD
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k<MODE><<<blocks, 64>>>(d, in, 1); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0); k<MODE><<<blocks, 64>>>(d, in, 2); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    double cols = (double)blocks * ROWS * NCOL;                 // wave-columns
+    double per_simd = cols / (256 * 4);
+    printf("%-44s %8.3f ms  %.2f cycles per column per SIMD @2.4GHz\n", name, ms, ms * 1e-3 * 2.4e9 / per_simd);
+}
+int main() {
+    unsigned *d, *in; (void)hipMalloc(&d, 256 * 16 * 64 * 4); (void)hipMalloc(&in, 4096); (void)hipMemset(in, 5, 4096);
+    run<0>("A: v_perm + v_add_u32 + 2 v_pk_max_u16", d, in);
+    run<1>("B: ds_bpermute + v_add_u32 + 2 v_pk_max_u16", d, in);
+    return 0;
+}
