@@ -238,3 +238,29 @@ def test_detect_middle_golden_and_oracle(i):
     assert recs.tobytes() == o_recs.tobytes()
     assert np.array_equal(cnt, o_cnt)
     assert (recs["exit_status"] == 997).sum() > 10
+
+
+def test_empty_batch_and_api_misuse():
+    det = scanner.factory(kit="PBC096")
+    assert det.detect_barcode_batch([], []) == []
+    d = det.descriptor()
+    kit = native.NativeKit(d)
+    bases, offsets = native.pack_reads([])
+    cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+    recs = ctx().scan(kit, bases, offsets, counts=cnt)
+    assert len(recs) == 0 and cnt.sum() == 0
+    hip = native.HipLibrary.get()
+    # non-monotonic offsets are rejected, not read out of bounds
+    bad = np.array([0, 10, 5], dtype=np.uint64)
+    out = np.zeros(2, dtype=native.RESULT_DTYPE)
+    rc = hip.lib.qcat_scan_batch(ctx().handle, kit.handle, np.zeros(16, dtype=np.uint8).ctypes.data, bad.ctypes.data, 2,
+                                 out.ctypes.data, None)
+    assert rc == -1 and b"non-decreasing" in hip.lib.qcat_last_error()
+    assert hip.lib.qcat_scan_batch(None, kit.handle, None, offsets.ctypes.data, 0, out.ctypes.data, None) == -1
+    # a 5'-only kit cannot be used for the kit vote
+    k5 = native.NativeKit(det.descriptor(ends=native.ENDS_5P))
+    with pytest.raises(RuntimeError, match="QCAT_ENDS_BOTH"):
+        ctx().detect_kit(k5, *native.pack_reads(["ACGT" * 50]))
+    # fetching results of a different batch size than the last scan is an error
+    out3 = np.zeros(3, dtype=native.RESULT_DTYPE)
+    assert hip.lib.qcat_ctx_fetch_results(ctx().handle, out3.ctypes.data, 3) == -1
