@@ -16,6 +16,9 @@ __global__ void __launch_bounds__(64, 4) k(unsigned* out, const unsigned* in, un
     unsigned tbl[NCOL]; us2 h[NCOL + 1];
     for (int j = 0; j < NCOL; ++j) { tbl[j] = in[(j * 64 + threadIdx.x) & 1023] | 0x00010001u; asm volatile("" : "+v"(tbl[j])); h[j] = U(j * 0x00010001u); }
     h[NCOL] = U(0);
+    unsigned codes[NCOL];
+    for (int j = 0; j < NCOL; ++j) codes[j] = __builtin_amdgcn_readfirstlane(in[j] & 7);
+    unsigned zero = __builtin_amdgcn_readfirstlane(in[100] & 0);
     unsigned special = seed * 3 + 1;
     asm volatile("" : "+v"(special));
     for (int i = 0; i < ROWS; ++i) {
@@ -23,18 +26,44 @@ __global__ void __launch_bounds__(64, 4) k(unsigned* out, const unsigned* in, un
         unsigned sel = (q & 0x00030003u) | 0x0C000C00u;
         int addr = (int)((q & 63u) << 2);
         us2 left = U(i * 0x00010001u), carry = left;
+        if (MODE == 3) asm volatile("s_set_gpr_idx_on 0, 0x1");
+        unsigned P0 = q & 0x00030003u, P1 = P0 + 0x00010001u, P2 = P0 ^ 0x00020002u, P3 = P0 + 0x00030003u,
+                 P4 = 0x00010001u, P5 = 0x00020002u, P6 = 0x00020002u, P7 = 0;
 #pragma unroll
         for (int j = 0; j < NCOL; ++j) {
             unsigned w;
-            if (MODE == 0) w = __builtin_amdgcn_perm(special, tbl[j], sel);
-            else w = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)tbl[j]);
             us2 up = h[j + 1];
-            us2 d = U(X(carry) + w);
+            us2 d;
+            if (MODE == 2) {
+                // C: VGPR-indexing mode: d = P[t_j] + diag in ONE full-rate add; P[0..7] pinned to v40..v47
+                unsigned dd;
+                const unsigned tj = codes[j];
+                asm volatile("s_set_gpr_idx_on %[t], 0x1\n\tv_add_u32 %[d], v40, %[c]\n\ts_set_gpr_idx_off"
+                             : [d] "=&v"(dd), "+{v40}"(P0), "+{v41}"(P1), "+{v42}"(P2), "+{v43}"(P3),
+                               "+{v44}"(P4), "+{v45}"(P5), "+{v46}"(P6), "+{v47}"(P7)
+                             : [t] "s"(tj), [c] "v"(X(carry)));
+                d = U(dd);
+            } else if (MODE == 3) {
+                // E: index mode stays on for the whole row; only the index changes per column
+                unsigned dd;
+                const unsigned tj = codes[j];
+                asm volatile("s_set_gpr_idx_idx %[t]\n\tv_add_u32 %[d], v40, %[c]\n\ts_set_gpr_idx_idx 0"
+                             : [d] "=&v"(dd), "+{v40}"(P0), "+{v41}"(P1), "+{v42}"(P2), "+{v43}"(P3),
+                               "+{v44}"(P4), "+{v45}"(P5), "+{v46}"(P6), "+{v47}"(P7)
+                             : [t] "s"(tj), [c] "v"(X(carry)));
+                d = U(dd);
+            } else {
+                unsigned w;
+                if (MODE == 0) w = __builtin_amdgcn_perm(special, tbl[j], sel);
+                else w = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)tbl[j]);
+                d = U(X(carry) + w);
+            }
             carry = up;
             left = __builtin_elementwise_max(__builtin_elementwise_max(d, up), left);
             h[j + 1] = left;
         }
     }
+    if (MODE == 3) asm volatile("s_set_gpr_idx_off");
     unsigned acc = 0;
     for (int j = 0; j <= NCOL; ++j) acc += X(h[j]);
     out[blockIdx.x * 64 + threadIdx.x] = acc;
@@ -54,5 +83,7 @@ int main() {
     unsigned *d, *in; (void)hipMalloc(&d, 256 * 16 * 64 * 4); (void)hipMalloc(&in, 4096); (void)hipMemset(in, 5, 4096);
     run<0>("A: v_perm + v_add_u32 + 2 v_pk_max_u16", d, in);
     run<1>("B: ds_bpermute + v_add_u32 + 2 v_pk_max_u16", d, in);
+    run<2>("C: gpr-idx v_add_u32 + 2 v_pk_max_u16", d, in);
+    run<3>("E: gpr-idx kept on, s_set_gpr_idx_idx per column", d, in);
     return 0;
 }
