@@ -47,6 +47,14 @@ extern "C" int qcat_device_count(void) {
     return n;
 }
 
+// temporary device allocation released on every exit path
+struct DevTemp {
+    void* p = nullptr;
+    ~DevTemp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 // ------------------------------------------------------------------------------------------
 // kit
 // ------------------------------------------------------------------------------------------
@@ -454,8 +462,9 @@ extern "C" int qcat_batch_synthesize(qcat_ctx* c, const qcat_kit* ckit, const qc
     SynthSetup s; std::string err;
     if ((rc = synth_setup(kit->hk, sp, kd->ascii, &s, &err))) return set_err(rc, err);
     const uint32_t n = sp->n_reads;
-    uint64_t* d_lens = nullptr;
-    HIPCHK(hipMalloc((void**)&d_lens, ((size_t)n + 1) * 8));
+    DevTemp lens_buf;
+    HIPCHK(lens_buf.alloc(((size_t)n + 1) * 8));
+    uint64_t* d_lens = lens_buf.as<uint64_t>();
     uint32_t blocks = (n + 255) / 256;
     // the read index space is global: `seed` identifies the data set, reads [first, first+n) are
     // produced here (first = 0; shards pass distinct seeds or use qcat_synth_read for offsets)
@@ -469,13 +478,13 @@ extern "C" int qcat_batch_synthesize(qcat_ctx* c, const qcat_kit* ckit, const qc
     b->device = c->device; b->n_reads = n; b->n_bases = offs[n];
     hipError_t e1 = hipMalloc((void**)&b->bases, b->n_bases + 16);
     hipError_t e2 = hipMalloc((void**)&b->offsets, ((size_t)n + 1) * 8);
-    if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipFree(d_lens); qcat_batch_destroy(b); return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for synthetic batch"); }
+    if (e1 != hipSuccess || e2 != hipSuccess) { qcat_batch_destroy(b); return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for synthetic batch"); }
     HIPCHK(hipMemcpyAsync(b->offsets, offs.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     if (n) hipLaunchKernelGGL(k_synth_write, dim3(blocks), dim3(256), 0, c->stream, s.p, s.t5, s.t3,
                               (int)s.has5, (int)s.has3, (uint64_t)0, n, b->offsets, b->bases);
-    HIPCHK(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_lens);
-    HIPCHK(hipGetLastError());
+    hipError_t es = hipStreamSynchronize(c->stream);
+    if (es == hipSuccess) es = hipGetLastError();
+    if (es != hipSuccess) { qcat_batch_destroy(b); return set_err(QCAT_ERR_DEVICE, std::string("qcat_batch_synthesize: ") + hipGetErrorString(es)); }
     *out = b;
     return 0;
 }
@@ -553,12 +562,13 @@ extern "C" int qcat_detect_kit(qcat_ctx* c, const qcat_kit* ckit, const uint8_t*
     int rc = qcat_batch_upload(c, bases, offsets, n_reads, &b);
     if (rc) return rc;
     rc = scan_resident_impl(c, kit, b, false, 0, true);
-    unsigned long long* d = nullptr;
+    DevTemp vote_buf;
     if (!rc && n_reads) {
         KitOnDevice* kd = nullptr;
         rc = kit_on_device(kit, c->device, &kd);
         hipError_t e = hipSuccess;
-        if (!rc) e = hipMalloc((void**)&d, 2 * MAX_T * 8);
+        if (!rc) e = vote_buf.alloc(2 * MAX_T * 8);
+        unsigned long long* d = vote_buf.as<unsigned long long>();
         if (!rc && e == hipSuccess) e = hipMemsetAsync(d, 0, MAX_T * 8, c->stream);
         if (!rc && e == hipSuccess) e = hipMemsetAsync(d + MAX_T, 0xFF, MAX_T * 8, c->stream);
         if (!rc && e == hipSuccess) {
@@ -570,7 +580,6 @@ extern "C" int qcat_detect_kit(qcat_ctx* c, const qcat_kit* ckit, const uint8_t*
         }
         if (!rc && e != hipSuccess) rc = set_err(QCAT_ERR_DEVICE, std::string("qcat_detect_kit: ") + hipGetErrorString(e));
     }
-    if (d) (void)hipFree(d);
     qcat_batch_destroy(b);
     if (rc) return rc;
     for (int t = 0; t < nt; ++t) {

@@ -263,7 +263,10 @@ class NativeKit(object):
     def __del__(self):
         h = getattr(self, "handle", None)
         if h:
-            self.hip.lib.qcat_kit_destroy(h)
+            try:
+                self.hip.lib.qcat_kit_destroy(h)
+            except Exception:            # interpreter shutdown: the library may already be gone
+                pass
             self.handle = None
 
 
@@ -280,7 +283,10 @@ class NativeContext(object):
     def __del__(self):
         h = getattr(self, "handle", None)
         if h:
-            self.hip.lib.qcat_ctx_destroy(h)
+            try:
+                self.hip.lib.qcat_ctx_destroy(h)
+            except Exception:
+                pass
             self.handle = None
 
     def detect_kit(self, kit, bases, offsets):
