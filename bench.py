@@ -42,6 +42,32 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (the
+    GPU boxes expose 256 hardware threads but run containers under a CPU quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2: "<quota> <period>" or "max ..."
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (IOError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / per
+        except (IOError, ValueError):
+            quota = None
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,10 +239,7 @@ def main():
         # ---- CPU baseline + parity on a bounded sample of rank 0's shard ---------------------
         if not a.no_cpu_baseline:
             import oracle_lib
-            try:
-                ncpu = len(os.sched_getaffinity(0))          # cores this process may actually use
-            except AttributeError:
-                ncpu = os.cpu_count() or 1
+            ncpu = usable_cores()
 
             def sample_reads(n):
                 buf = np.zeros(4096, dtype=np.uint8)
