@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(64, 4) k(unsigned* out, const unsigned* in, un
         us2 left = U(i * 0x00010001u), carry = left;
         if (MODE == 3) asm volatile("s_set_gpr_idx_on 0, 0x1");
         unsigned P0 = q & 0x00030003u, P1 = P0 + 0x00010001u, P2 = P0 ^ 0x00020002u, P3 = P0 + 0x00030003u,
-                 P4 = 0x00010001u, P5 = 0x00020002u, P6 = 0x00020002u, P7 = 0;
+                 P4 = P0 + 0x00010001u * (i & 3), P5 = 0x00020002u, P6 = 0x00020002u, P7 = 0;
 #pragma unroll
         for (int j = 0; j < NCOL; ++j) {
             unsigned w;
@@ -43,6 +43,10 @@ __global__ void __launch_bounds__(64, 4) k(unsigned* out, const unsigned* in, un
                                "+{v44}"(P4), "+{v45}"(P5), "+{v46}"(P6), "+{v47}"(P7)
                              : [t] "s"(tj), [c] "v"(X(carry)));
                 d = U(dd);
+            } else if (MODE == 4) {
+                // F: static target letters (what per-kit code generation would give): d = diag + P[t_j]
+                const unsigned pj = (j % 5 == 0) ? P0 : (j % 5 == 1) ? P1 : (j % 5 == 2) ? P2 : (j % 5 == 3) ? P3 : P4;
+                d = U(X(carry) + pj);
             } else if (MODE == 3) {
                 // E: index mode stays on for the whole row; only the index changes per column
                 unsigned dd;
@@ -85,5 +89,6 @@ int main() {
     run<1>("B: ds_bpermute + v_add_u32 + 2 v_pk_max_u16", d, in);
     run<2>("C: gpr-idx v_add_u32 + 2 v_pk_max_u16", d, in);
     run<3>("E: gpr-idx kept on, s_set_gpr_idx_idx per column", d, in);
+    run<4>("F: static letters: v_add_u32 + 2 v_pk_max_u16", d, in);
     return 0;
 }
