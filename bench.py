@@ -204,11 +204,11 @@ def main():
                     "algorithmic_bytes_per_launch": a.reads * bytes_per_read,
                     "avg_launch_ms": round(avg[dom], 4),
                     "kernels_avg_ms": {k: round(v, 4) for k, v in avg.items()},
-                    "note": "integer DP: VALU-issue bound, not HBM bound (SURVEY.md 8d); see valu"}
+                    "note": "integer DP (u16 and exact-integer fp16 lanes): VALU-issue bound, not HBM bound (SURVEY.md 8d); see valu"}
         out = {"metric": "reads/sec demultiplexed", "value": round(value, 1), "unit": "reads/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None, "dtype": "u16/f16 (exact small integers)", "data": "synthetic",
                "config": {"workload": "%s: %d synthetic reads/GPU, kit %s (%s), %s, error rate %.2f, "
                                       "~%d nt reads" % (a.workload, a.reads, kit_name or "DUAL", mode,
                                                         "5' end only" if ends == native.ENDS_5P else "5'+3' ends with trims",
@@ -269,29 +269,44 @@ def main():
             mism = int(np.count_nonzero(o != recs[:n_sample]))
             # reference-defined DP cells per read on the probe (second figure)
             lays = det.layouts
-            cells = 0
-            n_end = 1 if ends == native.ENDS_5P else 2
+            cells_a = cells_b = 0
             tl = sum(l.get_adapter_length() for l in lays)
             for t in tr1:
-                cells += int(t["window_len"]) * tl
+                cells_a += int(t["window_len"]) * tl
                 lay = lays[int(t["used_tpl"])]
                 for s in range(2 if mode == "dual" else 1):
                     bs = lay.get_barcode_set(s)
                     tlen = (len(lay.get_upstream_context(cfg.barcode_context_length, s)) + len(bs[0].sequence)
                             + len(lay.get_downstream_context(cfg.barcode_context_length, s)))
-                    cells += len(bs) * int(t["region_len"][s]) * tlen
-            cells_per_read = cells / float(probe)
+                    cells_b += len(bs) * int(t["region_len"][s]) * tlen
+            cells_a /= float(probe)
+            cells_b /= float(probe)
             out["cpu_baseline"] = {"value": round(all_cores, 1), "unit": "reads/s", "cores": ncpu, "kind": "port",
                                    "sample": "first %d reads of rank 0's shard, oracle/qcat_oracle.c with OpenMP over "
                                              "%d threads (1 thread: %.0f reads/s on %d reads)" % (n_sample, ncpu, one_thread, probe)}
             out["parity"] = {"checked_reads": n_sample, "mismatches_vs_oracle": mism}
-            out["valu"] = {"dp_cells_per_read": round(cells_per_read, 1),
-                           "cell_updates_per_s": round(value * cells_per_read, 1),
-                           "peak_cells_per_s": 256 * 4 * 2.4e9 * 128 / 14.0,
-                           "frac_of_valu_peak": round(value * cells_per_read / (256 * 4 * 2.4e9 * 128 / 14.0), 4),
-                           "note": "VALU-issue ceiling of the packed kernel: per column one wave retires 128 cells with "
-                                   "v_perm_b32 (4 cyc) + v_add_u32 (2) + 2 x v_pk_max_u16 (4+4) = 14 cycles/SIMD "
-                                   "(issue rates measured by tools/valu_rate.hip), 1024 SIMDs, 2.4 GHz nominal"}
+            # VALU-issue ceilings: one wave retires 128 cells per column; cycles per column from the issue
+            # rates tools/valu_rate.hip measures on this chip (profiles/r01_valu_issue_rates.txt)
+            simd_hz = 256 * 4 * 2.4e9
+            cyc_a = 4.17 + 2.73 + 4.15 + 4.15      # v_perm_b32 + v_add_u32 + 2 x v_pk_max_u16
+            cyc_b = 4.17 + 4.18 + 4.20             # v_perm_b32 + v_pk_add_f16 + v_pk_maximum3_f16
+            ceil_a, ceil_b = simd_hz * 128 / cyc_a, simd_hz * 128 / cyc_b
+            valu = {"unit": "DP cell updates/s", "dp_cells_per_read": round(cells_a + cells_b, 1)}
+            ideal_s = 0.0
+            for name, cells, ceil, kern in (("adapter", cells_a, ceil_a, "k_adapter_packed"),
+                                            ("barcode", cells_b, ceil_b, "k_barcode_packed")):
+                ms = avg.get(kern)
+                per_launch = cells * a.reads
+                ideal_s += per_launch / ceil
+                valu[name] = {"cells_per_read": round(cells, 1), "kernel_ms": ms, "ceiling": round(ceil, 1),
+                              "achieved": round(per_launch / (ms * 1e-3), 1) if ms else None,
+                              "frac": round(per_launch / (ms * 1e-3) / ceil, 4) if ms else None}
+            valu["frac_of_valu_peak"] = round(ideal_s / (elapsed / a.steps), 4)
+            valu["note"] = ("ceiling = 1024 SIMDs x 2.4 GHz x 128 cells / cycles per column; adapter kernel (u16 lanes): "
+                            "v_perm_b32 + v_add_u32 + 2 x v_pk_max_u16 = %.2f cycles; barcode kernel (fp16 lanes): v_perm_b32 + "
+                            "v_pk_add_f16 + v_pk_maximum3_f16 = %.2f cycles; frac_of_valu_peak = ideal DP time of both "
+                            "kernels / whole step time" % (cyc_a, cyc_b))
+            out["valu"] = valu
         print(json.dumps(out))
         sys.stdout.flush()
     lib.qcat_batch_destroy(batch)

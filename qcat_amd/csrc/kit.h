@@ -65,6 +65,7 @@ struct DevKit {
     int32_t n_barcode_slots, n_kit_slots, n_buckets;
     int32_t scan_middle;        // --detect-middle enabled
     int32_t fast_ok;            // every template/set is eligible for the packed fast path
+    int32_t barcode_f16;        // barcode tables hold binary16 high bytes (fp16-lane barcode kernels)
     uint32_t special_adapter;   // v_perm pool bytes for query codes N, X, other, PAD (adapter)
     uint32_t special_barcode;   //   "    (barcode alignments)
     int8_t amat[49], bmat[49];

@@ -8,6 +8,7 @@
 #define NCOL 44
 #define ROWS 2048
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 __device__ inline us2 U(unsigned x) { return __builtin_bit_cast(us2, x); }
 __device__ inline unsigned X(us2 x) { return __builtin_bit_cast(unsigned, x); }
 
@@ -47,6 +48,16 @@ __global__ void __launch_bounds__(64, 4) k(unsigned* out, const unsigned* in, un
                 // F: static target letters (what per-kit code generation would give): d = diag + P[t_j]
                 const unsigned pj = (j % 5 == 0) ? P0 : (j % 5 == 1) ? P1 : (j % 5 == 2) ? P2 : (j % 5 == 3) ? P3 : P4;
                 d = U(X(carry) + pj);
+            } else if (MODE == 5 || MODE == 6) {
+                // G/H: fp16 lanes (biased scores are small exact integers): d = diag + w in v_pk_add_f16, then ONE
+                // v_pk_maximum3_f16 for max(d, up, left).  G looks w up with v_perm, H has static letters.
+                unsigned w5;
+                if (MODE == 5) w5 = __builtin_amdgcn_perm(special, tbl[j], sel);
+                else w5 = (j % 5 == 0) ? P0 : (j % 5 == 1) ? P1 : (j % 5 == 2) ? P2 : (j % 5 == 3) ? P3 : P4;
+                const h2 dd = __builtin_bit_cast(h2, X(carry)) + __builtin_bit_cast(h2, w5);
+                const h2 ll = __builtin_elementwise_maximum(__builtin_elementwise_maximum(dd, __builtin_bit_cast(h2, X(up))), __builtin_bit_cast(h2, X(left)));
+                carry = up; left = U(__builtin_bit_cast(unsigned, ll)); h[j + 1] = left;
+                continue;
             } else if (MODE == 3) {
                 // E: index mode stays on for the whole row; only the index changes per column
                 unsigned dd;
@@ -73,8 +84,8 @@ __global__ void __launch_bounds__(64, 4) k(unsigned* out, const unsigned* in, un
     out[blockIdx.x * 64 + threadIdx.x] = acc;
 }
 
-template <int MODE> void run(const char* name, unsigned* d, unsigned* in) {
-    const int blocks = 256 * 16;        // 16 one-wave blocks per CU = 4 waves per SIMD
+template <int MODE> void run(const char* name, unsigned* d, unsigned* in, int per_cu = 16) {
+    const int blocks = 256 * per_cu;    // 16 one-wave blocks per CU = 4 waves per SIMD
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     k<MODE><<<blocks, 64>>>(d, in, 1); (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0); k<MODE><<<blocks, 64>>>(d, in, 2); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
@@ -84,11 +95,18 @@ template <int MODE> void run(const char* name, unsigned* d, unsigned* in) {
     printf("%-44s %8.3f ms  %.2f cycles per column per SIMD @2.4GHz\n", name, ms, ms * 1e-3 * 2.4e9 / per_simd);
 }
 int main() {
-    unsigned *d, *in; (void)hipMalloc(&d, 256 * 16 * 64 * 4); (void)hipMalloc(&in, 4096); (void)hipMemset(in, 5, 4096);
+    unsigned *d, *in; (void)hipMalloc(&d, 256 * 32 * 64 * 4); (void)hipMalloc(&in, 4096); (void)hipMemset(in, 5, 4096);
     run<0>("A: v_perm + v_add_u32 + 2 v_pk_max_u16", d, in);
     run<1>("B: ds_bpermute + v_add_u32 + 2 v_pk_max_u16", d, in);
     run<2>("C: gpr-idx v_add_u32 + 2 v_pk_max_u16", d, in);
     run<3>("E: gpr-idx kept on, s_set_gpr_idx_idx per column", d, in);
     run<4>("F: static letters: v_add_u32 + 2 v_pk_max_u16", d, in);
+    run<5>("G: v_perm + v_pk_add_f16 + v_pk_maximum3_f16", d, in);
+    run<6>("H: static letters + v_pk_add_f16 + v_pk_maximum3_f16", d, in);
+    run<6>("H at 2 waves/SIMD", d, in, 8);
+    run<6>("H at 1 wave/SIMD", d, in, 4);
+    run<5>("G at 2 waves/SIMD", d, in, 8);
+    run<5>("G at 1 wave/SIMD", d, in, 4);
+    run<0>("A at 2 waves/SIMD", d, in, 8);
     return 0;
 }

@@ -54,7 +54,11 @@ __global__ void __launch_bounds__(256) k(unsigned* out, unsigned seed) {
         else if (OP == 36) asm volatile("v_min_u32 %0, %0, %1" : "+v"(r) : "v"(b)); \
         else if (OP == 37) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(r) : "v"(b)); \
         else if (OP == 38) asm volatile("v_max_u16 %0, %0, %1" : "+v"(r) : "v"(b)); \
-        else if (OP == 39) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c));
+        else if (OP == 39) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c)); \
+        else if (OP == 40) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c)); \
+        else if (OP == 41) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c)); \
+        else if (OP == 42) asm volatile("v_maximum3_f32 %0, %0, %1, %2" : "+v"(r) : "v"(b), "v"(c)); \
+        else if (OP == 43) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r) : "v"(b), "v"(c));
         REP8(ONE(a0) ONE(a1) ONE(a2) ONE(a3) ONE(a4) ONE(a5) ONE(a6) ONE(a7))
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (unsigned)(qa0 + qa1 + qa2 + qa3 + qa4 + qa5 + qa6 + qa7);
@@ -85,5 +89,6 @@ int main() {
     run<24>("v_cvt_f32_ubyte1", d); run<25>("v_sub_u32", d); run<26>("v_and_b32", d); run<27>("v_xor_b32", d); run<28>("v_max_i32", d);
     run<29>("v_max_f16", d); run<30>("v_max3_f16", d); run<31>("v_add3_u32", d); run<32>("v_lshlrev_b32", d); run<33>("v_mov_b32", d);
     run<34>("v_pk_add_f32", d); run<35>("v_pk_fma_f32", d); run<36>("v_min_u32", d); run<37>("v_pk_add_i16", d); run<38>("v_max_u16", d);
+    run<40>("v_pk_maximum3_f16", d); run<41>("v_pk_minimum3_f16", d); run<42>("v_maximum3_f32", d); run<43>("v_bitop3_b32", d);
     return 0;
 }
