@@ -47,6 +47,8 @@ struct DevSet {
     int32_t min_raw_pass;       // smallest raw with raw*100.0/tlen >= min_quality
     int32_t min_raw_conflict;   // smallest raw with raw*100.0/tlen >= conflict_min_score
     int32_t min_raw_middle;     // smallest raw with raw*100.0/tlen >= middle_min_score (--detect-middle)
+    int32_t static_kernel;      // generated static-letter kernel of this group (kernels_static.inc), -1: none
+    int32_t case_off;           // ids blob: n case indices into that kernel
 };
 
 struct DevTpl {
@@ -68,6 +70,7 @@ struct DevKit {
     int32_t barcode_f16;        // barcode tables hold binary16 high bytes (fp16-lane barcode kernels)
     uint32_t special_adapter;   // v_perm pool bytes for query codes N, X, other, PAD (adapter)
     uint32_t special_barcode;   //   "    (barcode alignments)
+    uint32_t letter_tbl_barcode[4];   // score dword of a column whose target letter is A, T, G, C (static kernels)
     int8_t amat[49], bmat[49];
     int8_t pad_[2];
     DevTpl tpl[MAX_T];

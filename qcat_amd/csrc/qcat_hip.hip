@@ -22,6 +22,7 @@
 #include "kernels_common.inc"
 #include "kernels_generic.inc"
 #include "kernels_packed.inc"
+#include "kernels_static.inc"
 
 using namespace qk;
 
@@ -83,6 +84,7 @@ extern "C" int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {
     std::string err;
     int rc = kit_prepare(desc, &k->hk, &err);
     if (rc) { delete k; return set_err(rc, err); }
+    static_match(&k->hk);
     *out = k;
     return 0;
 }
