@@ -58,6 +58,7 @@ struct DevTpl {
     int32_t code_off;           // codes blob: len template codes
     int32_t tbl_off;            // tables blob: `width` dwords, right-aligned (-1: not eligible)
     int32_t width;              // register-array width class of the packed adapter kernel
+    int32_t static_kernel;      // generated static-letter adapter kernel (kernels_static.inc), -1: none
     DevSet sets[2];
 };
 
@@ -71,6 +72,11 @@ struct DevKit {
     uint32_t special_adapter;   // v_perm pool bytes for query codes N, X, other, PAD (adapter)
     uint32_t special_barcode;   //   "    (barcode alignments)
     uint32_t letter_tbl_barcode[4];   // score dword of a column whose target letter is A, T, G, C (static kernels)
+    // static adapter kernels: binary16 bits of the biased adapter score W'(query code, target letter x),
+    // x = A, T, G, C, N; pool_lo/hi[x] = low / high bytes for query A, T, G, C
+    uint32_t adapter_pool_lo[5], adapter_pool_hi[5];
+    uint16_t adapter_w16[5 * 8];
+    int32_t adapter_f16;        // the binary16 adapter DP is exact for this kit (static adapter kernels allowed)
     int8_t amat[49], bmat[49];
     int8_t pad_[2];
     DevTpl tpl[MAX_T];
