@@ -131,11 +131,14 @@ static int kit_on_device(qcat_kit* k, int device, KitOnDevice** out) {
 // ------------------------------------------------------------------------------------------
 // batch (reads resident in device memory)
 // ------------------------------------------------------------------------------------------
+constexpr size_t BATCH_SLACK = 64;
 struct qcat_batch {
     int device = 0;
     uint32_t n_reads = 0;
     uint64_t n_bases = 0;
-    uint8_t* bases = nullptr;      // n_bases (+16 slack)
+    uint8_t* bases_alloc = nullptr;   // BATCH_SLACK + n_bases + BATCH_SLACK bytes
+    uint8_t* bases = nullptr;      // bases_alloc + BATCH_SLACK: k_pack_windows reads whole aligned dwords
+                                   // up to 19 bytes before / after a read's window
     uint64_t* offsets = nullptr;   // n_reads + 1
 };
 
@@ -241,7 +244,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     const size_t n_ends = (size_t)n * ends;
     if (n_ends >= (1ull << 31)) return set_err(QCAT_ERR_UNSUPPORTED, "batch too large (>= 2^31 read ends)");
 
-    if ((rc = grow(&c->win, &c->cap_win, n_ends * WIN_STRIDE))) return rc;
+    if ((rc = grow(&c->win, &c->cap_win, n_ends * WIN_STRIDE + 64))) return rc;     // + slack: k_job_gather reads whole dwords
     if ((rc = grow(&c->wlen, &c->cap_wlen, n_ends))) return rc;
     if ((rc = grow(&c->recs, &c->cap_recs, n_ends))) return rc;
     if ((rc = grow(&c->results, &c->cap_reads, (size_t)n))) return rc;
@@ -352,7 +355,7 @@ extern "C" void qcat_batch_destroy(qcat_batch* b) {
     if (!b) return;
     int cur = 0; (void)hipGetDevice(&cur);
     (void)hipSetDevice(b->device);
-    (void)hipFree(b->bases); (void)hipFree(b->offsets);
+    (void)hipFree(b->bases_alloc); (void)hipFree(b->offsets);
     (void)hipSetDevice(cur);
     delete b;
 }
@@ -374,7 +377,8 @@ extern "C" int qcat_batch_upload(qcat_ctx* c, const uint8_t* bases, const uint64
     HIPCHK(hipSetDevice(c->device));
     qcat_batch* b = new qcat_batch();
     b->device = c->device; b->n_reads = n_reads; b->n_bases = offsets[n_reads];
-    hipError_t e1 = hipMalloc((void**)&b->bases, b->n_bases + 16);
+    hipError_t e1 = hipMalloc((void**)&b->bases_alloc, b->n_bases + 2 * BATCH_SLACK);
+    if (e1 == hipSuccess) b->bases = b->bases_alloc + BATCH_SLACK;
     hipError_t e2 = hipMalloc((void**)&b->offsets, ((size_t)n_reads + 1) * 8);
     if (e1 != hipSuccess || e2 != hipSuccess) { qcat_batch_destroy(b); return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch"); }
     if (b->n_bases) HIPCHK(hipMemcpyAsync(b->bases, bases, b->n_bases, hipMemcpyHostToDevice, c->stream));
@@ -478,7 +482,8 @@ extern "C" int qcat_batch_synthesize(qcat_ctx* c, const qcat_kit* ckit, const qc
     for (uint32_t i = 0; i < n; ++i) offs[i + 1] = offs[i] + lens[i];
     qcat_batch* b = new qcat_batch();
     b->device = c->device; b->n_reads = n; b->n_bases = offs[n];
-    hipError_t e1 = hipMalloc((void**)&b->bases, b->n_bases + 16);
+    hipError_t e1 = hipMalloc((void**)&b->bases_alloc, b->n_bases + 2 * BATCH_SLACK);
+    if (e1 == hipSuccess) b->bases = b->bases_alloc + BATCH_SLACK;
     hipError_t e2 = hipMalloc((void**)&b->offsets, ((size_t)n + 1) * 8);
     if (e1 != hipSuccess || e2 != hipSuccess) { qcat_batch_destroy(b); return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for synthetic batch"); }
     HIPCHK(hipMemcpyAsync(b->offsets, offs.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
