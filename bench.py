@@ -191,7 +191,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
                 tj = json.load(fh).get(a.workload)
-            if tj and dom and tj["kernel"] == dom:
+            if tj and dom and dom in tj["kernel"]:
                 traffic = int(tj["bytes"] * (a.reads / float(tj["reads_per_launch"])))
         except (IOError, ValueError, KeyError):
             traffic = None
@@ -288,24 +288,28 @@ def main():
             # VALU-issue ceilings: one wave retires 128 cells per column; cycles per column from the issue
             # rates tools/valu_rate.hip measures on this chip (profiles/r01_valu_issue_rates.txt)
             simd_hz = 256 * 4 * 2.4e9
-            cyc_a = 4.17 + 2.73 + 4.15 + 4.15      # v_perm_b32 + v_add_u32 + 2 x v_pk_max_u16
-            cyc_b = 4.17 + 4.18 + 4.20             # v_perm_b32 + v_pk_add_f16 + v_pk_maximum3_f16
-            ceil_a, ceil_b = simd_hz * 128 / cyc_a, simd_hz * 128 / cyc_b
+            cyc = {"k_adapter_packed": 4.17 + 2.73 + 4.15 + 4.15,    # v_perm_b32 + v_add_u32 + 2 x v_pk_max_u16 (u16 lanes)
+                   "k_barcode_packed": 4.17 + 4.18 + 4.20,           # v_perm_b32 + v_pk_add_f16 + v_pk_maximum3_f16
+                   "k_adapter_static": 4.18 + 4.20,                  # v_pk_add_f16 + v_pk_maximum3_f16 (static letters)
+                   "k_barcode_static": 4.18 + 4.20}
             valu = {"unit": "DP cell updates/s", "dp_cells_per_read": round(cells_a + cells_b, 1)}
             ideal_s = 0.0
-            for name, cells, ceil, kern in (("adapter", cells_a, ceil_a, "k_adapter_packed"),
-                                            ("barcode", cells_b, ceil_b, "k_barcode_packed")):
-                ms = avg.get(kern)
+            for name, cells, kerns in (("adapter", cells_a, ("k_adapter_static", "k_adapter_packed")),
+                                       ("barcode", cells_b, ("k_barcode_static", "k_barcode_packed"))):
+                ran = [kn for kn in kerns if kn in avg]
+                if not ran:
+                    continue
+                ms = sum(avg[kn] for kn in ran)
+                ceil = simd_hz * 128 / max(cyc[kn] for kn in ran)      # mixed kits: priced at the slower instruction mix
                 per_launch = cells * a.reads
                 ideal_s += per_launch / ceil
-                valu[name] = {"cells_per_read": round(cells, 1), "kernel_ms": ms, "ceiling": round(ceil, 1),
-                              "achieved": round(per_launch / (ms * 1e-3), 1) if ms else None,
-                              "frac": round(per_launch / (ms * 1e-3) / ceil, 4) if ms else None}
+                valu[name] = {"kernels": ran, "cells_per_read": round(cells, 1), "kernel_ms": round(ms, 4), "ceiling": round(ceil, 1),
+                              "achieved": round(per_launch / (ms * 1e-3), 1), "frac": round(per_launch / (ms * 1e-3) / ceil, 4)}
             valu["frac_of_valu_peak"] = round(ideal_s / (elapsed / a.steps), 4)
-            valu["note"] = ("ceiling = 1024 SIMDs x 2.4 GHz x 128 cells / cycles per column; adapter kernel (u16 lanes): "
-                            "v_perm_b32 + v_add_u32 + 2 x v_pk_max_u16 = %.2f cycles; barcode kernel (fp16 lanes): v_perm_b32 + "
-                            "v_pk_add_f16 + v_pk_maximum3_f16 = %.2f cycles; frac_of_valu_peak = ideal DP time of both "
-                            "kernels / whole step time" % (cyc_a, cyc_b))
+            valu["note"] = ("ceiling = 1024 SIMDs x 2.4 GHz x 128 cells per wave-column / VALU issue cycles per column "
+                            "(issue rates measured by tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt): static-letter kernels "
+                            "v_pk_add_f16 + v_pk_maximum3_f16 = 8.38 cycles; table kernels 12.55 (fp16 lanes) / 15.2 (u16 lanes); "
+                            "frac_of_valu_peak = ideal DP time of both phases / whole step time")
             out["valu"] = valu
         print(json.dumps(out))
         sys.stdout.flush()

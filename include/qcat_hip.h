@@ -166,6 +166,24 @@ void qcat_kit_destroy(qcat_kit* kit);
  * (dual: barcode bucket = slot1 * n_barcode_slots + slot2; cli.py:366-383, scanner_base.py:680-689) */
 int  qcat_kit_count_buckets(const qcat_kit* kit);
 
+/* Which kernels a prepared kit will run (no reference counterpart: the reference has one code
+ * path; this reports the library's choice so callers and tests can see a fall-back).
+ *   packed            1: packed inter-read DP kernels, 0: generic per-read kernel (affine gaps,
+ *                     scores outside the packed range, templates / targets too long)
+ *   barcode_f16       1: barcode DP in exact-integer binary16 lanes, 0: u16 lanes
+ *   adapter_f16       1: the binary16 adapter DP is exact for this kit
+ *   n_templates / n_static_templates   adapter templates / those bound to a generated
+ *                     static-letter kernel (templates of the built-in kits)
+ *   n_groups / n_static_groups         (template, barcode set) groups / those whose every
+ *                     target is a case of a generated static-letter kernel */
+typedef struct qcat_kit_info {
+    int32_t packed, barcode_f16, adapter_f16;
+    int32_t n_templates, n_static_templates;
+    int32_t n_groups, n_static_groups;
+    int32_t reserved;
+} qcat_kit_info;
+int  qcat_kit_describe(const qcat_kit* kit, qcat_kit_info* out);
+
 int  qcat_ctx_create(int device, qcat_ctx** out);
 void qcat_ctx_destroy(qcat_ctx* ctx);
 

@@ -89,6 +89,24 @@ extern "C" int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {
     return 0;
 }
 
+extern "C" int qcat_kit_describe(const qcat_kit* k, qcat_kit_info* out) {
+    if (!k || !out) return set_err(QCAT_ERR_ARG, "qcat_kit_describe: null argument");
+    const DevKit& d = k->hk.dk;
+    memset(out, 0, sizeof *out);
+    out->packed = (d.fast_ok && packed_supported(d)) ? 1 : 0;
+    out->barcode_f16 = d.barcode_f16; out->adapter_f16 = d.adapter_f16;
+    out->n_templates = d.nt;
+    const int nsets = d.mode == QCAT_MODE_DUAL ? 2 : 1;
+    for (int t = 0; t < d.nt; ++t) {
+        if (d.tpl[t].static_kernel >= 0) out->n_static_templates++;
+        for (int s = 0; s < nsets; ++s) {
+            out->n_groups++;
+            if (d.tpl[t].sets[s].static_kernel >= 0) out->n_static_groups++;
+        }
+    }
+    return 0;
+}
+
 extern "C" void qcat_kit_destroy(qcat_kit* k) {
     if (!k) return;
     int cur = 0;

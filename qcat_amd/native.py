@@ -170,6 +170,13 @@ class KitDescriptor(object):
         return C.byref(self.desc)
 
 
+class KitInfo(C.Structure):
+    """qcat_kit_info (include/qcat_hip.h): which kernels a prepared kit runs."""
+    _fields_ = [("packed", C.c_int32), ("barcode_f16", C.c_int32), ("adapter_f16", C.c_int32),
+                ("n_templates", C.c_int32), ("n_static_templates", C.c_int32),
+                ("n_groups", C.c_int32), ("n_static_groups", C.c_int32), ("reserved", C.c_int32)]
+
+
 def pack_reads(read_sequences):
     """list of str/bytes/None -> (uint8 bases, uint64 offsets[n+1])."""
     chunks = []
@@ -210,6 +217,7 @@ class HipLibrary(object):
             "qcat_kit_create": (C.c_int, [C.POINTER(KitDesc), C.POINTER(vp)]),
             "qcat_kit_destroy": (None, [vp]),
             "qcat_kit_count_buckets": (C.c_int, [vp]),
+            "qcat_kit_describe": (C.c_int, [vp, C.POINTER(KitInfo)]),
             "qcat_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
             "qcat_ctx_destroy": (None, [vp]),
             "qcat_scan_batch": (C.c_int, [vp, vp, vp, vp, u32, vp, vp]),
@@ -259,6 +267,13 @@ class NativeKit(object):
         h = C.c_void_p()
         self.hip.check(self.hip.lib.qcat_kit_create(descriptor.byref(), C.byref(h)))
         self.handle = h
+
+    def describe(self):
+        """dict of qcat_kit_info: packed / fp16 eligibility and how many templates and barcode groups
+        are bound to generated static-letter kernels."""
+        info = KitInfo()
+        self.hip.check(self.hip.lib.qcat_kit_describe(self.handle, C.byref(info)))
+        return {name: int(getattr(info, name)) for name, _ in KitInfo._fields_ if name != "reserved"}
 
     def __del__(self):
         h = getattr(self, "handle", None)

@@ -1,0 +1,143 @@
+"""Static-letter kernels (qcat_amd/csrc/kernels_static.inc + static_generated.inc).
+
+CPU: the generated source is in sync with resources/kits.json, and every built-in kit selection
+binds ALL of its templates and barcode groups to generated kernels (a silent fall-back to the table
+kernels would only cost speed, so it has to be caught here).
+GPU: the static, the table (fp16 and u16 lanes) and the single-stream paths produce byte-identical
+records, traces and per-barcode rows, and equal the CPU oracle -- including reads with N / X / other
+letters, which take the slow score path of the static adapter kernels."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+from qcat_amd import native, scanner
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _generator():
+    spec = importlib.util.spec_from_file_location("gen_static_kernels", os.path.join(ROOT, "tools", "gen_static_kernels.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_generated_source_is_in_sync_with_the_kit_bundle():
+    gen = _generator()
+    text, n_kernels, n_targets, n_templates = gen.render()
+    assert open(gen.OUT).read() == text, "run python tools/gen_static_kernels.py"
+    assert n_kernels >= 16 and n_targets >= 600 and n_templates >= 14
+
+
+@pytest.mark.parametrize("mode", ["epi2me", "dual"])
+def test_every_builtin_kit_selection_is_fully_static(mode):
+    for kit in [None] + sorted(scanner.get_kits()):
+        det = scanner.factory(mode=mode, kit=kit)
+        info = native.NativeKit(det.descriptor()).describe()
+        assert info["packed"] == 1 and info["barcode_f16"] == 1 and info["adapter_f16"] == 1, (mode, kit, info)
+        assert info["n_static_templates"] == info["n_templates"] > 0, (mode, kit, info)
+        assert info["n_static_groups"] == info["n_groups"] > 0, (mode, kit, info)
+
+
+def test_unknown_targets_keep_the_table_kernels(tmp_path):
+    """a custom kit: PBC096's first template with a changed last letter and reversed barcodes -> no
+    registry hit; the same kit with the shipped sequences binds to the generated kernels"""
+    import yaml
+    det = scanner.factory(kit="PBC096")
+    lay = det.layouts[0]
+
+    def write(name, kit, seq, barcodes):
+        rows = [{"name": "barcode%02d" % (i + 1), "id": i + 1, "sequence": s, "fwd_strand": True} for i, s in enumerate(barcodes)]
+        data = {"kit": kit, "auto_detect": False, "description": "test kit", "sequence": seq, "trim_offset": 0,
+                "barcode_set_1": rows, "barcode_set_2": []}
+        (tmp_path / (name + ".yml")).write_text(yaml.safe_dump(data))
+
+    bcs = [b.sequence for b in lay.get_barcode_set(0)[:8]]
+    write("a", "CUSTOMA", lay.sequence[:-1] + ("A" if lay.sequence[-1] != "A" else "C"), [b[::-1] for b in bcs])
+    write("b", "CUSTOMB", lay.sequence, bcs)
+    info = native.NativeKit(scanner.factory(kit="CUSTOMA", kit_folder=str(tmp_path)).descriptor()).describe()
+    assert info["packed"] == 1 and info["n_static_templates"] == 0 and info["n_static_groups"] == 0
+    info = native.NativeKit(scanner.factory(kit="CUSTOMB", kit_folder=str(tmp_path)).descriptor()).describe()
+    assert info["n_static_templates"] == 1 and info["n_static_groups"] == 1
+
+
+# ---------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+_ctx = {}
+
+
+def ctx():
+    if "c" not in _ctx:
+        _ctx["c"] = native.NativeContext(0)
+    return _ctx["c"]
+
+
+def run(det, reads, ends=native.ENDS_BOTH):
+    d = det.descriptor(ends=ends)
+    kit = native.NativeKit(d)
+    bases, offsets = native.pack_reads(reads)
+    cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+    recs, traces, rows = ctx().scan(kit, bases, offsets, counts=cnt, trace=True, rows=True)
+    return d, recs.tobytes(), {n: traces[n].copy() for n in native.TRACE_DTYPE.names}, rows.copy(), cnt
+
+
+def same(a, b):
+    assert a[1] == b[1]
+    for n in a[2]:
+        assert np.array_equal(a[2][n], b[2][n]), n
+    assert np.array_equal(a[3], b[3])
+    assert np.array_equal(a[4], b[4])
+
+
+VARIANTS = [{"QCAT_HIP_NO_STATIC": "1"}, {"QCAT_HIP_NO_STATIC_ADAPTER": "1"}, {"QCAT_HIP_ONE_STREAM": "1"},
+            {"QCAT_HIP_NO_STATIC": "1", "QCAT_HIP_BARCODE_U16": "1"}, {"QCAT_HIP_CHUNK_BARCODES": "1"},
+            {"QCAT_HIP_CHUNK_BARCODES": "1000"}]
+
+
+@gpu
+@pytest.mark.parametrize("mode,kit,t5,t3,n", [
+    ("epi2me", "NBD103/NBD104", 1, 0, 1500), ("epi2me", "PBC096", 1, 0, 1200), ("epi2me", None, 3, 2, 500),
+    ("epi2me", "VMK001", 0, -1, 500), ("dual", None, 1, 0, 700)])
+def test_static_and_table_paths_agree_and_match_the_oracle(monkeypatch, mode, kit, t5, t3, n):
+    det = scanner.factory(mode=mode, kit=kit)
+    reads = synth.synth_batch(n, 77, det.layouts, t5, t3, error_rate=0.1)
+    reads += ["", "A", "ACGT" * 10, reads[0][:31], reads[1][:75]]
+    base = run(det, reads)
+    o_recs, o_cnt, o_traces, o_rows = oracle_lib.scan(base[0], reads, counts=True, trace=True, rows=True, threads=8)
+    assert base[1] == o_recs.tobytes()
+    assert np.array_equal(base[4], o_cnt) and np.array_equal(base[3], o_rows)
+    for name in native.TRACE_DTYPE.names:
+        assert np.array_equal(base[2][name], o_traces[name]), name
+    for env in VARIANTS:
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            same(base, run(det, reads))
+
+
+@gpu
+@pytest.mark.parametrize("kit", ["NBD103/NBD104", "RBK004", None])
+def test_reads_with_n_x_and_other_letters(kit):
+    """non-ACGT letters inside the windows: slow score path of the static adapter kernels and the
+    shared `special` pool of the barcode kernels"""
+    det = scanner.factory(kit=kit)
+    rng = np.random.RandomState(5)
+    reads = synth.synth_batch(600, 9, det.layouts, 1 if len(det.layouts) > 1 else 0, 0 if len(det.layouts) > 1 else -1,
+                              error_rate=0.06)
+    out = []
+    for i, r in enumerate(reads):
+        r = list(r)
+        for _ in range(i % 7):                          # 0..6 substitutions, biased to both ends
+            pos = rng.randint(0, min(len(r), 160)) if rng.rand() < 0.5 else len(r) - 1 - rng.randint(0, min(len(r), 160))
+            r[pos] = "NXRnx-*"[rng.randint(0, 7)]
+        out.append("".join(r))
+    base = run(det, out)
+    o_recs, o_cnt, o_traces, o_rows = oracle_lib.scan(base[0], out, counts=True, trace=True, rows=True, threads=8)
+    assert base[1] == o_recs.tobytes()
+    assert np.array_equal(base[3], o_rows)
+    for name in native.TRACE_DTYPE.names:
+        assert np.array_equal(base[2][name], o_traces[name]), name

@@ -9,7 +9,7 @@ tag = sys.argv[1]
 out = {"_comment": "HBM traffic of the dominant kernel per launch, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
        "passes, tools/profile.sh; per-dispatch averages in profiles/%s_*/summary.txt). bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: "
        "FETCH_SIZE/WRITE_SIZE are in KiB and gfx950's FETCH_SIZE reports half of a wide coalesced read stream "
-       "(MI355X_MICROARCH.md, HBM section); all width-class instantiations of the kernel that ran in the step are summed." % tag}
+       "(MI355X_MICROARCH.md, HBM section); all instantiations of the barcode DP kernel that ran in the step (static-letter kernels of every group, table kernels of every width class) are summed." % tag}
 for arg in sys.argv[2:]:
     wl, d = arg.split("=")
     tot = defaultdict(float)
@@ -17,11 +17,11 @@ for arg in sys.argv[2:]:
         per = defaultdict(list)
         with open(os.path.join(d, fn)) as fh:
             for row in csv.DictReader(fh):
-                if "k_barcode_packed" in row["Kernel_Name"] and row["Counter_Name"] == name:
+                if ("k_barcode_packed" in row["Kernel_Name"] or "k_barcode_static" in row["Kernel_Name"]) and row["Counter_Name"] == name:
                     per[row["Kernel_Name"]].append(float(row["Counter_Value"]))
         tot[name] = sum(sum(v) / len(v) for v in per.values())
     reads = 1000000
-    out[wl] = {"kernel": "k_barcode_packed", "reads_per_launch": reads, "fetch_size_kib": round(tot["FETCH_SIZE"], 1),
+    out[wl] = {"kernel": "k_barcode_static+k_barcode_packed", "reads_per_launch": reads, "fetch_size_kib": round(tot["FETCH_SIZE"], 1),
                "write_size_kib": round(tot["WRITE_SIZE"], 1), "bytes": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024)}
 with open(os.path.join(ROOT, "profiles", tag + "_traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
