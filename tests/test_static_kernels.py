@@ -141,3 +141,33 @@ def test_reads_with_n_x_and_other_letters(kit):
     assert np.array_equal(base[3], o_rows)
     for name in native.TRACE_DTYPE.names:
         assert np.array_equal(base[2][name], o_traces[name]), name
+
+
+def _scaled_barcode_cfg(scale):
+    from qcat_amd import config
+    cfg = config.qcatConfig()
+    cfg._matrix_barcode = config.ScoreMatrix(cfg.matrix_barcode.table.astype(np.int64) * scale)   # not configurable in the reference
+    return cfg
+
+
+def test_fp16_lanes_are_only_used_when_exact():
+    """binary16 barcode lanes need one-byte score encodings AND every DP value below 2048"""
+    det = scanner.factory(kit="PBC096")
+    assert native.NativeKit(det.descriptor(qcat_config=_scaled_barcode_cfg(3))).describe()["barcode_f16"] == 1    # W' = 5, 0
+    assert native.NativeKit(det.descriptor(qcat_config=_scaled_barcode_cfg(30))).describe()["barcode_f16"] == 0   # 32*64 > 2047
+    assert native.NativeKit(det.descriptor(qcat_config=_scaled_barcode_cfg(7))).describe()["barcode_f16"] == 0    # W' = 9 = 0x4880
+
+
+@gpu
+@pytest.mark.parametrize("scale", [3, 7, 30])
+def test_scaled_barcode_matrix_matches_the_oracle(scale):
+    det = scanner.factory(kit="PBC096")
+    cfg = _scaled_barcode_cfg(scale)
+    reads = synth.synth_batch(500, 3, det.layouts, 1, 0, error_rate=0.1)
+    d = det.descriptor(qcat_config=cfg)
+    kit = native.NativeKit(d)
+    bases, offsets = native.pack_reads(reads)
+    recs, traces, rows = ctx().scan(kit, bases, offsets, trace=True, rows=True)
+    o_recs, o_traces, o_rows = oracle_lib.scan(d, reads, trace=True, rows=True, threads=8)
+    assert recs.tobytes() == o_recs.tobytes()
+    assert np.array_equal(rows, o_rows)
