@@ -250,9 +250,16 @@ int  qcat_ctx_fetch_counts(qcat_ctx* ctx, int64_t* counts, int32_t n_buckets);
 void* qcat_ctx_counts_devptr(qcat_ctx* ctx);
 void* qcat_ctx_results_devptr(qcat_ctx* ctx);
 
-/* Kernel timing of the LAST qcat_scan_resident on this context, measured with hipEvents
- * recorded on the context's stream around each kernel (synchronises).  names[i] points to a
- * static string; returns the number of entries written (<= cap). */
+/* the context's HIP stream (hipStream_t): a caller that enqueues its own work on it -- e.g. the
+ * RCCL all-reduce of the count vector -- is ordered after the scan and before the next one
+ * without a host synchronisation. */
+void* qcat_ctx_stream(qcat_ctx* ctx);
+
+/* Kernel timing, measured with hipEvents recorded on the context's stream around each kernel
+ * phase: the AVERAGE over the qcat_scan_resident calls since the previous qcat_ctx_last_timing /
+ * qcat_ctx_set_timing (a ring of 64 scans; scans need no host synchronisation between them, this
+ * call synchronises once and empties the ring).  names[i] points to a static string; returns the
+ * number of entries written (<= cap). */
 int  qcat_ctx_last_timing(qcat_ctx* ctx, const char** names, float* ms, int cap);
 /* enable/disable per-kernel event timing (off by default: events serialise nothing but cost
  * a few microseconds per launch). */

@@ -181,12 +181,17 @@ struct qcat_ctx {
     // debug buffers
     int32_t* dbg_tpl = nullptr; size_t cap_dbg_tpl = 0;
     int16_t* dbg_rows = nullptr; size_t cap_dbg_rows = 0;
-    // timing
+    // timing: a ring of event sets, one per scan, so that timed scans need no host synchronisation
+    // between them; qcat_ctx_last_timing drains the ring
     bool timing = false;
     int force_generic = 0;
-    int n_timed = 0;
-    const char* timed_name[MAX_TIMED];
-    hipEvent_t ev[MAX_TIMED + 1];
+    static constexpr int TIME_RING = 64;
+    int n_timed = 0;                               // marks of the scan being recorded
+    int ring_used = 0;                             // recorded scans not yet drained (<= TIME_RING)
+    int ring_marks[TIME_RING];
+    const char* timed_name[TIME_RING][MAX_TIMED];
+    hipEvent_t evr[TIME_RING][MAX_TIMED + 1];
+    hipEvent_t* ev = nullptr;                      // event set of the scan being recorded
     bool ev_ready = false;
 };
 
@@ -213,7 +218,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->recs); (void)hipFree(c->results);
     (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows);
     packed_scratch_free(&c->packed);
-    if (c->ev_ready) for (int i = 0; i <= MAX_TIMED; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_ready) for (int r = 0; r < qcat_ctx::TIME_RING; ++r) for (int i = 0; i <= MAX_TIMED; ++i) (void)hipEventDestroy(c->evr[r][i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -222,10 +227,11 @@ extern "C" int qcat_ctx_set_timing(qcat_ctx* c, int enabled) {
     if (!c) return set_err(QCAT_ERR_ARG, "null context");
     HIPCHK(hipSetDevice(c->device));
     if (enabled && !c->ev_ready) {
-        for (int i = 0; i <= MAX_TIMED; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+        for (int r = 0; r < qcat_ctx::TIME_RING; ++r) for (int i = 0; i <= MAX_TIMED; ++i) HIPCHK(hipEventCreate(&c->evr[r][i]));
         c->ev_ready = true;
     }
     c->timing = enabled != 0;
+    c->ring_used = 0; c->n_timed = 0; c->ev = nullptr;
     return 0;
 }
 
@@ -241,10 +247,11 @@ static int grow(T** p, size_t* cap, size_t need) {
 }
 
 static void mark(qcat_ctx* c, const char* name) {
-    if (!c->timing || c->n_timed >= MAX_TIMED) return;
-    c->timed_name[c->n_timed] = name;
+    if (!c->timing || !c->ev || c->n_timed >= MAX_TIMED) return;
+    c->timed_name[c->ring_used - 1][c->n_timed] = name;
     (void)hipEventRecord(c->ev[c->n_timed + 1], c->stream);
     c->n_timed++;
+    c->ring_marks[c->ring_used - 1] = c->n_timed;
 }
 
 // core: scan a resident batch.  dbg: optional debug buffers sized by the caller.
@@ -276,9 +283,15 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     c->last_n_reads = n;
     c->last_buckets = hk.n_buckets;
     c->n_timed = 0;
+    c->ev = nullptr;
+    if (c->timing) {                               // next slot of the ring; a full ring restarts (oldest scans dropped)
+        if (c->ring_used >= qcat_ctx::TIME_RING) c->ring_used = 0;
+        c->ring_marks[c->ring_used] = 0;
+        c->ev = c->evr[c->ring_used++];
+    }
     HIPCHK(hipMemsetAsync(c->counts, 0, (size_t)hk.n_buckets * 8, c->stream));
     if (n == 0) return 0;
-    if (c->timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if (c->timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));   // (an empty batch returned above: its slot holds no marks)
 
     KitPtrs kp{kd->kit, kd->codes, kd->ids, kd->tables};
     {
@@ -350,6 +363,7 @@ extern "C" int qcat_ctx_fetch_counts(qcat_ctx* c, int64_t* counts, int32_t n_buc
     return 0;
 }
 
+extern "C" void* qcat_ctx_stream(qcat_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" void* qcat_ctx_counts_devptr(qcat_ctx* c) { return c ? c->counts : nullptr; }
 extern "C" void* qcat_ctx_results_devptr(qcat_ctx* c) { return c ? c->results : nullptr; }
 
@@ -358,11 +372,22 @@ extern "C" int qcat_ctx_last_timing(qcat_ctx* c, const char** names, float* ms, 
     if (!c->timing) return 0;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    int n = std::min(cap, c->n_timed);
-    for (int i = 0; i < n; ++i) {
-        names[i] = c->timed_name[i];
-        HIPCHK(hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    // average per mark over the recorded scans that have the same mark list as the newest one
+    const int last = c->ring_used - 1;
+    if (last < 0) return 0;
+    const int n = std::min(cap, c->ring_marks[last]);
+    for (int i = 0; i < n; ++i) { names[i] = c->timed_name[last][i]; ms[i] = 0.f; }
+    int scans = 0;
+    for (int r = 0; r <= last; ++r) {
+        if (c->ring_marks[r] != c->ring_marks[last]) continue;
+        bool same = true;
+        for (int i = 0; i < n; ++i) same = same && c->timed_name[r][i] == c->timed_name[last][i];
+        if (!same) continue;
+        for (int i = 0; i < n; ++i) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, c->evr[r][i], c->evr[r][i + 1])); ms[i] += t; }
+        ++scans;
     }
+    for (int i = 0; i < n; ++i) ms[i] /= (float)scans;
+    c->ring_used = 0; c->n_timed = 0; c->ev = nullptr;
     return n;
 }
 

@@ -218,6 +218,7 @@ class HipLibrary(object):
             "qcat_kit_destroy": (None, [vp]),
             "qcat_kit_count_buckets": (C.c_int, [vp]),
             "qcat_kit_describe": (C.c_int, [vp, C.POINTER(KitInfo)]),
+            "qcat_ctx_stream": (vp, [vp]),
             "qcat_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
             "qcat_ctx_destroy": (None, [vp]),
             "qcat_scan_batch": (C.c_int, [vp, vp, vp, vp, u32, vp, vp]),
