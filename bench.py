@@ -38,6 +38,9 @@ WORKLOADS = {
     "config2": ("epi2me", "NBD103/NBD104", native.ENDS_5P, 1, 0, 174),
     "config3": ("epi2me", "PBC096", native.ENDS_BOTH, 1, 0, 324),
     "dual": ("dual", None, native.ENDS_BOTH, 1, 0, 324),
+    # --detect-middle (every called read's interior is scanned on both strands);
+    # algorithmic bytes = both windows + the interior (~424 nt of a ~724-nt read) + the record
+    "middle": ("epi2me", "NBD103/NBD104", native.ENDS_BOTH, 1, 0, 324 + 424),
 }
 HBM_PEAK_GBS = 8000.0
 
@@ -103,7 +106,7 @@ def main():
     mode, kit_name, ends, t5, t3, bytes_per_read = WORKLOADS[a.workload]
     det = scanner.factory(mode=mode, kit=kit_name, device=local_rank)
     cfg = qconfig.qcatConfig()
-    desc = det.descriptor(qcat_config=cfg, ends=ends)
+    desc = det.descriptor(qcat_config=cfg, ends=ends, scan_middle=(a.workload == "middle"))
     hip = native.HipLibrary.get()
     lib = hip.lib
     kit = native.NativeKit(desc)

@@ -23,6 +23,8 @@
 #include "kernels_generic.inc"
 #include "kernels_packed.inc"
 #include "kernels_static.inc"
+#include "kernels_middle.inc"
+#include "static_registry.inc"
 
 using namespace qk;
 
@@ -176,6 +178,13 @@ struct qcat_ctx {
     qcat_result* results = nullptr;
     unsigned long long* counts = nullptr;
     PackedScratch packed;
+    // packed --detect-middle (kernels_middle.inc): M-end sort tables and per-slot arrays
+    MidTables* mid_tables = nullptr;
+    uint8_t* mid_generic = nullptr; size_t cap_mid_generic = 0;
+    uint32_t* mid_slot = nullptr; size_t cap_mid_slot = 0;
+    uint32_t* mid_sorted = nullptr; int32_t* mid_len = nullptr; int32_t* mid_fallback = nullptr;
+    EndRec* mid_recs = nullptr; AdapterBest* mid_bests = nullptr;
+    size_t cap_mid_slots = 0, cap_mid_bests = 0;
     uint32_t last_n_reads = 0;
     int last_buckets = 0;
     // debug buffers
@@ -218,6 +227,8 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->recs); (void)hipFree(c->results);
     (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows);
     packed_scratch_free(&c->packed);
+    (void)hipFree(c->mid_tables); (void)hipFree(c->mid_generic); (void)hipFree(c->mid_slot); (void)hipFree(c->mid_sorted);
+    (void)hipFree(c->mid_len); (void)hipFree(c->mid_fallback); (void)hipFree(c->mid_recs); (void)hipFree(c->mid_bests);
     if (c->ev_ready) for (int r = 0; r < qcat_ctx::TIME_RING; ++r) for (int i = 0; i <= MAX_TIMED; ++i) (void)hipEventDestroy(c->evr[r][i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -252,6 +263,72 @@ static void mark(qcat_ctx* c, const char* name) {
     (void)hipEventRecord(c->ev[c->n_timed + 1], c->stream);
     c->n_timed++;
     c->ring_marks[c->ring_used - 1] = c->n_timed;
+}
+
+// packed --detect-middle is possible when every template has a generated static-letter adapter
+// kernel (all built-in kits) and the kit's slots fit the sort tables
+static bool middle_packed_ok(const DevKit& hk) {
+    if (!hk.adapter_f16 || hk.n_kit_slots > MID_MAX_KITS || getenv("QCAT_HIP_MIDDLE_GENERIC")) return false;
+    for (int t = 0; t < hk.nt; ++t) if (hk.tpl[t].static_kernel < 0) return false;
+    return true;
+}
+
+// the interior scan of every called read on the packed kernels (kernels_middle.inc); leaves
+// c->mid_generic[r] = 1 for reads it could not take (interior longer than the length classes)
+static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_batch* b, uint32_t n) {
+    hipStream_t st = c->stream;
+    int rc;
+    const size_t slots = ((size_t)2 * n + (size_t)hk.n_kit_slots * MID_CLASSES * PK_TILE + PK_TILE - 1) / PK_TILE * PK_TILE;
+    if (slots >= (1ull << 31)) return set_err(QCAT_ERR_UNSUPPORTED, "batch too large for the packed interior scan");
+    if (!c->mid_tables) HIPCHK(hipMalloc((void**)&c->mid_tables, sizeof(MidTables)));
+    if ((rc = grow(&c->mid_generic, &c->cap_mid_generic, (size_t)n))) return rc;
+    if ((rc = grow(&c->mid_slot, &c->cap_mid_slot, (size_t)n))) return rc;
+    if (slots > c->cap_mid_slots) {
+        (void)hipFree(c->mid_sorted); (void)hipFree(c->mid_len); (void)hipFree(c->mid_fallback); (void)hipFree(c->mid_recs);
+        c->mid_sorted = nullptr; c->mid_len = nullptr; c->mid_fallback = nullptr; c->mid_recs = nullptr; c->cap_mid_slots = 0;
+        HIPCHK(hipMalloc((void**)&c->mid_sorted, slots * 4));
+        HIPCHK(hipMalloc((void**)&c->mid_len, slots * 4));
+        HIPCHK(hipMalloc((void**)&c->mid_fallback, slots * 4));
+        HIPCHK(hipMalloc((void**)&c->mid_recs, slots * sizeof(EndRec)));
+        c->cap_mid_slots = slots;
+    }
+    if ((rc = grow(&c->mid_bests, &c->cap_mid_bests, slots * (size_t)hk.nt))) return rc;
+    HIPCHK(hipMemsetAsync(c->mid_tables, 0, sizeof(MidTables), st));
+    HIPCHK(hipMemsetAsync(c->mid_slot, 0xFF, (size_t)n * 4, st));
+    HIPCHK(hipMemsetAsync(c->mid_sorted, 0xFF, slots * 4, st));
+    HIPCHK(hipMemsetAsync(c->mid_len, 0, slots * 4, st));
+    HIPCHK(hipMemsetAsync(c->mid_fallback, 0, slots * 4, st));
+    const uint32_t rblocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_mid_count, dim3(rblocks), dim3(256), 0, st, kp.kit, b->offsets, n, c->results, c->mid_tables, c->mid_generic);
+    hipLaunchKernelGGL(k_mid_offsets, dim3(1), dim3(1024), 0, st, c->mid_tables);
+    hipLaunchKernelGGL(k_mid_scatter, dim3((n + 256 * MID_SCAT - 1) / (256 * MID_SCAT)), dim3(256), 0, st,
+                       kp.kit, b->offsets, n, c->results, c->mid_tables, c->mid_sorted, c->mid_len, c->mid_fallback, c->mid_slot);
+    // adapter phase: one launch per template (tiles of other kits record "did not compete"), the
+    // launches of a scan run concurrently
+    PackedScratch* sc = &c->packed;
+    if ((rc = packed_prepare(st, hk, (uint32_t)slots, sc))) return set_err(rc, packed_last_error());
+    const uint32_t tiles = (uint32_t)(slots / PK_TILE);
+    fork_join(sc, st, hk.nt, [&](int t, hipStream_t q) {
+        MiddleAdapterArgs ma{kp, b->bases, b->offsets, c->mid_sorted, c->mid_len, c->mid_tables,
+                             c->mid_bests + (size_t)t * slots, t};
+        launch_adapter_middle(hk.tpl[t].static_kernel, dim3(tiles), q, ma);
+    });
+    {
+        const uint32_t fblocks = (uint32_t)std::min<uint64_t>((slots + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_adapter_finish, dim3(fblocks), dim3(256), 0, st, kp.kit, c->mid_len, (uint32_t)slots,
+                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback);
+    }
+    const int nsets = hk.mode == QCAT_MODE_DUAL ? 2 : 1;
+    rc = packed_barcode(st, kp, hk, (uint32_t)slots, c->mid_recs, sc, [&](uint32_t max_tiles) {
+        const uint64_t gthreads = (uint64_t)max_tiles * 64 * (WIN_STRIDE / 16);
+        hipLaunchKernelGGL(k_mid_gather, dim3((uint32_t)((gthreads + 255) / 256)), dim3(256), 0, st,
+                           b->bases, b->offsets, hk.max_align, c->mid_sorted, c->mid_recs, sc->sorted, sc->jt, nsets,
+                           sc->tilebuf, sc->tmeta);
+    }, (int16_t*)nullptr, 0u, [](const char*) {});
+    if (rc) return set_err(rc, packed_last_error());
+    hipLaunchKernelGGL(k_mid_finalize, dim3((n + 255) / 256), dim3(256), 0, st, kp.kit, c->mid_recs, c->mid_slot, n, c->results);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // core: scan a resident batch.  dbg: optional debug buffers sized by the caller.
@@ -324,8 +401,14 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
                            kp, c->recs, b->offsets, n, c->results, middle ? nullptr : c->counts);
         mark(c, "k_finalize");
         if (middle) {
+            const uint8_t* only = nullptr;
+            if (use_packed && middle_packed_ok(hk)) {
+                if ((rc = middle_packed(c, kp, hk, b, n))) return rc;
+                only = c->mid_generic;                  // interiors beyond the packed path's length classes
+                mark(c, "k_middle_packed");
+            }
             hipLaunchKernelGGL(k_scan_middle, dim3((n + GEN_THREADS - 1) / GEN_THREADS), dim3(GEN_THREADS), 0, c->stream,
-                               kp, b->bases, b->offsets, n, c->results);
+                               kp, b->bases, b->offsets, n, c->results, only);
             hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, c->stream, kp, c->results, n, c->counts);
             mark(c, "k_scan_middle");
         }

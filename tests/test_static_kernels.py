@@ -171,3 +171,49 @@ def test_scaled_barcode_matrix_matches_the_oracle(scale):
     o_recs, o_traces, o_rows = oracle_lib.scan(d, reads, trace=True, rows=True, threads=8)
     assert recs.tobytes() == o_recs.tobytes()
     assert np.array_equal(rows, o_rows)
+
+
+@gpu
+@pytest.mark.parametrize("mode,kit,t5,t3", [("epi2me", "NBD103/NBD104", 1, 0), ("epi2me", "PBC096", 1, 0),
+                                            ("epi2me", None, 3, 2), ("dual", None, 1, 0), ("epi2me", "RBK004", 0, -1)])
+def test_packed_detect_middle_matches_generic_kernel_and_oracle(monkeypatch, mode, kit, t5, t3):
+    """--detect-middle on the packed interior kernels (kernels_middle.inc): chimeric reads (adapters in
+    the interior, either strand), interiors spanning several 152-row blocks and length classes, reads too
+    short to have an interior, one interior beyond the packed length classes (general kernel), N runs."""
+    det = scanner.factory(mode=mode, kit=kit, scan_middle_adapter=True)
+    base = synth.synth_batch(260, 4242, det.layouts, t5, t3, error_rate=0.08)
+    rng = np.random.RandomState(11)
+    comp = {"A": "T", "T": "A", "G": "C", "C": "G"}
+    reads = []
+    for j, r in enumerate(base):
+        kind = j % 6
+        if kind == 0:
+            reads.append(r + r)                                         # same barcode at both ends, adapters inside
+        elif kind == 1:
+            rc = "".join(comp.get(ch, "N") for ch in reversed(r))
+            reads.append(r[:len(r) // 2] + rc + r[len(r) // 2:])       # reverse-strand adapter inside
+        elif kind == 2:
+            reads.append(r[:150 + rng.randint(0, 400)] + r[-170:])     # short interiors, many length classes
+        elif kind == 3:
+            reads.append(r + "".join("ACGT"[rng.randint(0, 4)] for _ in range(rng.randint(100, 2500))) + r)
+        elif kind == 4:
+            reads.append(r[:300] + "N" * rng.randint(1, 90) + r[300:])
+        else:
+            reads.append(r)
+    reads += ["", "ACGT" * 70, base[0][:299], base[1][:300], base[2][:301], base[3][:364], base[4][:365],
+              base[5] + "".join("ACGT"[rng.randint(0, 4)] for _ in range(17000)) + base[5]]
+    d = det.descriptor()
+    kit_h = native.NativeKit(d)
+    bases, offsets = native.pack_reads(reads)
+    cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+    recs = ctx().scan(kit_h, bases, offsets, counts=cnt)
+    with monkeypatch.context() as m:
+        m.setenv("QCAT_HIP_MIDDLE_GENERIC", "1")
+        cnt_g = np.zeros(d.n_count_buckets, dtype=np.int64)
+        recs_g = ctx().scan(kit_h, bases, offsets, counts=cnt_g)
+    assert recs.tobytes() == recs_g.tobytes()
+    assert np.array_equal(cnt, cnt_g)
+    o_recs, o_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
+    assert recs.tobytes() == o_recs.tobytes()
+    assert np.array_equal(cnt, o_cnt)
+    assert (recs["exit_status"] == 997).sum() > 20
