@@ -72,13 +72,32 @@ struct KitOnDevice {
     int32_t* ids = nullptr;
     uint32_t* tables = nullptr;
     char* ascii = nullptr;
+    // static-letter kernels compiled for this kit at run time (qcat_kit_attach_code)
+    hipModule_t jit_module = nullptr;
+    hipFunction_t jit_ad[MAX_T] = {}, jit_am[MAX_T] = {}, jit_bc[MAX_T * 2] = {};
 };
 
 struct qcat_kit {
     HostKit hk;
     std::mutex mu;
     KitOnDevice dev[MAX_DEVICES];
+    std::vector<uint8_t> jit_code;                 // code object (gfx950) with qj_ad_<t>, qj_am_<t>, qj_bc_<t*2+s>
+    bool jit_tpl[MAX_T] = {}, jit_grp[MAX_T * 2] = {};
 };
+
+// launch of a run-time generated kernel (kernel id >= QCAT_JIT_BASE): the scan in progress on this
+// thread publishes its kit's function table here
+static thread_local const KitOnDevice* g_jit = nullptr;
+
+namespace qk {
+static inline void jit_launch(int kind, int index, dim3 grid, hipStream_t stream, const void* args) {
+    hipFunction_t f = nullptr;
+    if (g_jit) f = kind == QCAT_JIT_ADAPTER ? g_jit->jit_ad[index] : (kind == QCAT_JIT_MIDDLE ? g_jit->jit_am[index] : g_jit->jit_bc[index]);
+    if (!f) { g_packed_err = "run-time generated kernel missing from the kit's code object"; return; }
+    void* params[1] = {const_cast<void*>(args)};
+    (void)hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, PK_WAVES * 64, 1, 1, 0, stream, params, nullptr);
+}
+}  // namespace qk
 
 extern "C" int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {
     if (!out) return set_err(QCAT_ERR_ARG, "qcat_kit_create: null output pointer");
@@ -88,6 +107,31 @@ extern "C" int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {
     if (rc) { delete k; return set_err(rc, err); }
     static_match(&k->hk);
     *out = k;
+    return 0;
+}
+
+extern "C" int qcat_kit_attach_code(qcat_kit* k, const void* code, uint64_t size,
+                                    const int32_t* template_flags, const int32_t* group_flags) {
+    if (!k || !code || !size || !template_flags || !group_flags) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: null argument");
+    std::lock_guard<std::mutex> lock(k->mu);
+    for (int d = 0; d < MAX_DEVICES; ++d)
+        if (k->dev[d].ready) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: the kit is already in use on a device");
+    if (!k->jit_code.empty()) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: code already attached");
+    HostKit& h = k->hk;
+    DevKit& d = h.dk;
+    k->jit_code.assign((const uint8_t*)code, (const uint8_t*)code + size);
+    const int nsets = d.mode == QCAT_MODE_DUAL ? 2 : 1;
+    for (int t = 0; t < d.nt; ++t) {
+        if (template_flags[t] && d.adapter_f16 && d.tpl[t].static_kernel < 0) { d.tpl[t].static_kernel = QCAT_JIT_BASE + t; k->jit_tpl[t] = true; }
+        for (int s = 0; s < nsets; ++s) {
+            DevSet& q = d.tpl[t].sets[s];
+            if (!group_flags[t * 2 + s] || !d.barcode_f16 || q.static_kernel >= 0 || q.n <= 0) continue;
+            q.static_kernel = QCAT_JIT_BASE + t * 2 + s;
+            q.case_off = (int32_t)h.ids.size();          // generated for exactly this kit: case b = barcode b
+            for (int b = 0; b < q.n; ++b) h.ids.push_back(b);
+            k->jit_grp[t * 2 + s] = true;
+        }
+    }
     return 0;
 }
 
@@ -119,6 +163,7 @@ extern "C" void qcat_kit_destroy(qcat_kit* k) {
         (void)hipSetDevice(d);
         (void)hipFree(kd.kit); (void)hipFree(kd.codes); (void)hipFree(kd.ids);
         (void)hipFree(kd.tables); (void)hipFree(kd.ascii);
+        if (kd.jit_module) (void)hipModuleUnload(kd.jit_module);
     }
     (void)hipSetDevice(cur);
     delete k;
@@ -142,6 +187,22 @@ static int kit_on_device(qcat_kit* k, int device, KitOnDevice** out) {
         HIPCHK(hipMemcpy(kd.ids, h.ids.data(), h.ids.size() * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(kd.tables, h.tables.data(), h.tables.size() * 4, hipMemcpyHostToDevice));
         if (!h.ascii.empty()) HIPCHK(hipMemcpy(kd.ascii, h.ascii.data(), h.ascii.size(), hipMemcpyHostToDevice));
+        if (!k->jit_code.empty()) {
+            HIPCHK(hipModuleLoadData(&kd.jit_module, k->jit_code.data()));
+            char name[32];
+            for (int t = 0; t < h.dk.nt; ++t) {
+                if (k->jit_tpl[t]) {
+                    snprintf(name, sizeof name, "qj_ad_%d", t);
+                    HIPCHK(hipModuleGetFunction(&kd.jit_ad[t], kd.jit_module, name));
+                    snprintf(name, sizeof name, "qj_am_%d", t);
+                    HIPCHK(hipModuleGetFunction(&kd.jit_am[t], kd.jit_module, name));
+                }
+                for (int s2 = 0; s2 < 2; ++s2) if (k->jit_grp[t * 2 + s2]) {
+                    snprintf(name, sizeof name, "qj_bc_%d", t * 2 + s2);
+                    HIPCHK(hipModuleGetFunction(&kd.jit_bc[t * 2 + s2], kd.jit_module, name));
+                }
+            }
+        }
         kd.ready = true;
     }
     *out = &kd;
@@ -371,6 +432,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     if (c->timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));   // (an empty batch returned above: its slot holds no marks)
 
     KitPtrs kp{kd->kit, kd->codes, kd->ids, kd->tables};
+    g_jit = kd;
     {
         uint64_t threads = (uint64_t)n_ends * (WIN_STRIDE / 16);
         uint32_t blocks = (uint32_t)((threads + 255) / 256);

@@ -1,0 +1,167 @@
+"""Run-time generation of static-letter kernels for kits that are not in the built-in bundle.
+
+The library ships generated column chains for every template and barcode target of
+``resources/kits.json`` (``csrc/static_generated.inc``); a custom kit (``--kit-folder``) runs the
+slower table kernels.  This module emits the same chains for ONE kit descriptor, compiles them with
+``hipcc --genco`` against ``csrc/jit_prelude.inc`` and hands the code object to the library
+(``qcat_kit_attach_code``).  It is optional and off by default (a compile takes several seconds):
+
+    QCAT_AMD_JIT=1           compile for every kit that is not fully covered by the built-in kernels
+    QCAT_AMD_JIT_CACHE=dir   where code objects are kept (default ~/.cache/qcat_amd)
+
+There is no reference counterpart (the reference has one code path); results are identical on
+every path, which ``tests/test_jit.py`` checks against the CPU oracle.
+"""
+import ctypes as C
+import hashlib
+import os
+import shutil
+import subprocess
+import tempfile
+
+from .codes import ASCII_TO_CODE
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+ARCH = "gfx950"
+MAX_TEMPLATES = 16
+_LETTER = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4}          # code -> E[] index: A, T, G, C (+ N in templates)
+
+
+def enabled():
+    return os.environ.get("QCAT_AMD_JIT", "0") not in ("", "0")
+
+
+def hipcc_path():
+    cand = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    return cand if os.path.exists(cand) else None
+
+
+def _codes(seq):
+    return [int(ASCII_TO_CODE[ord(c)]) for c in seq]
+
+
+def _chain(codes):
+    """the column chain of tools/gen_static_kernels.py: chunks of four, the next chunk's diagonal term
+    formed before the current chunk's writes"""
+    e = ["E[%d]" % _LETTER[c] for c in codes]
+    out = ["QS_BEGIN(%s)" % e[0]]
+    n = len(codes)
+    for j in range(0, n, 4):
+        k = min(4, n - j)
+        inner = e[j + 1:j + k]
+        if j + k < n:
+            out.append("QS_CHUNK4(%d, %s)" % (j + 1, ", ".join(inner + [e[j + k]])))
+        else:
+            out.append("QS_LAST%d(%d%s)" % (k, j + 1, "".join(", " + x for x in inner)))
+    return " ".join(out)
+
+
+def generate(descriptor, skip_templates=(), skip_groups=()):
+    """(source text, template flags, group flags) for the templates / (template, set) groups of
+    ``descriptor`` that can take static-letter kernels and are not in the skip lists"""
+    n = int(descriptor.desc.barcode_context_length)
+    nsets = 2 if descriptor.mode == "dual" else 1
+    tpl_flags = [0] * MAX_TEMPLATES
+    grp_flags = [0] * (2 * MAX_TEMPLATES)
+    parts = ['#include "jit_prelude.inc"\n', "namespace qk {\n"]
+    entry = []
+    for t, lay in enumerate(descriptor.layouts):
+        tcodes = _codes(lay.sequence)
+        if t not in skip_templates and all(c <= 4 for c in tcodes) and 1 <= len(tcodes) <= 128:
+            m = len(tcodes)
+            parts.append("struct QACJ_%d { static __device__ __forceinline__ void run(h2 (&h)[%d], h2& carry, h2& left, "
+                         "const h2 (&E)[5]) { %s } };\n" % (t, m + 1, _chain(tcodes)))
+            entry.append('extern "C" __global__ void __launch_bounds__(qk::PK_WAVES * 64, QS_ADAPTER_WAVES(%d)) '
+                         "qj_ad_%d(qk::StaticAdapterArgs a) { qk::adapter_static_body<%d, qk::QACJ_%d>(a); }\n" % (m, t, m, t))
+            entry.append('extern "C" __global__ void __launch_bounds__(qk::PK_WAVES * 64, QS_ADAPTER_WAVES(%d)) '
+                         "qj_am_%d(qk::MiddleAdapterArgs a) { qk::adapter_middle_body<%d, qk::QACJ_%d>(a); }\n" % (m, t, m, t))
+            tpl_flags[t] = 1
+        for s in range(nsets):
+            g = t * 2 + s
+            bs = lay.get_barcode_set(s)
+            if g in skip_groups or not bs:
+                continue
+            up, dn = lay.get_upstream_context(n, s), lay.get_downstream_context(n, s)
+            targets = [_codes(up + b.sequence + dn) for b in bs]
+            m = len(targets[0])
+            if any(len(x) != m or any(c > 3 for c in x) for x in targets) or not 1 <= m <= 64:
+                continue
+            for b, tg in enumerate(targets):
+                parts.append("struct QSCJ_%d_%d { static __device__ __forceinline__ void run(h2 (&h)[%d], h2& carry, h2& left, "
+                             "const h2 (&E)[4]) { %s } };\n" % (g, b, m + 1, _chain(tg)))
+            parts.append("struct QSGJ_%d {\n    static constexpr int M = %d;\n"
+                         "    static __device__ __forceinline__ u32 run(int kc, const uint8_t* qbuf, int lane, int Lmax, h2 gL2, "
+                         "u32 special, const u32 (&ltr)[4], h2 rowoff, h2 coloff) {\n        switch (kc) {\n" % (g, m))
+            for b in range(len(targets)):
+                parts.append("        case %d: return static_barcode_rows<M, QSCJ_%d_%d>(qbuf, lane, Lmax, gL2, special, ltr, rowoff, coloff);\n"
+                             % (b, g, b))
+            parts.append("        default: return 0;\n        }\n    }\n};\n")
+            entry.append('extern "C" __global__ void __launch_bounds__(qk::PK_WAVES * 64, 4) '
+                         "qj_bc_%d(qk::StaticArgs a) { qk::barcode_static_body<qk::QSGJ_%d>(a); }\n" % (g, g))
+            grp_flags[g] = 1
+    parts.append("}  // namespace qk\n")
+    return "".join(parts + entry), tpl_flags, grp_flags
+
+
+def _prelude_digest():
+    h = hashlib.sha1()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".inc", ".h")) and name != "static_generated.inc":
+            with open(os.path.join(CSRC, name), "rb") as fh:
+                h.update(name.encode())
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def compile_source(source):
+    """code object bytes for ``source`` (cached by content)"""
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("qcat_amd.jit: hipcc not found (set HIPCC); cannot generate kernels for this kit")
+    cache = os.environ.get("QCAT_AMD_JIT_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "qcat_amd")
+    key = hashlib.sha1((source + _prelude_digest() + ARCH).encode()).hexdigest()
+    path = os.path.join(cache, key + ".hsaco")
+    if os.path.exists(path):
+        with open(path, "rb") as fh:
+            return fh.read()
+    tmp = tempfile.mkdtemp(prefix="qcat_jit_")
+    try:
+        src = os.path.join(tmp, "kit.hip")
+        out = os.path.join(tmp, "kit.hsaco")
+        with open(src, "w") as fh:
+            fh.write(source)
+        cmd = [hipcc, "--genco", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-w", "-I", CSRC, src, "-o", out]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if proc.returncode != 0 or not os.path.exists(out):
+            raise RuntimeError("qcat_amd.jit: hipcc failed:\n" + proc.stdout.decode(errors="replace")[-4000:])
+        with open(out, "rb") as fh:
+            blob = fh.read()
+        try:
+            os.makedirs(cache, exist_ok=True)
+            with open(path + ".tmp%d" % os.getpid(), "wb") as fh:
+                fh.write(blob)
+            os.replace(path + ".tmp%d" % os.getpid(), path)
+        except OSError:
+            pass                                    # read-only home: compile again next time
+        return blob
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def attach(native_kit):
+    """generate, compile and attach kernels for whatever the built-in registry left on the table
+    kernels; returns the kit's new ``describe()`` (unchanged when there was nothing to do)"""
+    info = native_kit.describe()
+    if (not info["packed"] or (info["n_static_templates"] == info["n_templates"]
+                               and info["n_static_groups"] == info["n_groups"])):
+        return info
+    source, tpl_flags, grp_flags = generate(native_kit.descriptor)
+    if not any(tpl_flags) and not any(grp_flags):
+        return info
+    blob = compile_source(source)
+    hip = native_kit.hip
+    tf = (C.c_int32 * MAX_TEMPLATES)(*tpl_flags)
+    gf = (C.c_int32 * (2 * MAX_TEMPLATES))(*grp_flags)
+    hip.check(hip.lib.qcat_kit_attach_code(native_kit.handle, blob, len(blob), tf, gf))
+    native_kit._jit_blob = blob                     # keep the buffer alive as long as the kit
+    return native_kit.describe()

@@ -218,6 +218,7 @@ class HipLibrary(object):
             "qcat_kit_destroy": (None, [vp]),
             "qcat_kit_count_buckets": (C.c_int, [vp]),
             "qcat_kit_describe": (C.c_int, [vp, C.POINTER(KitInfo)]),
+            "qcat_kit_attach_code": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.POINTER(i32), C.POINTER(i32)]),
             "qcat_ctx_stream": (vp, [vp]),
             "qcat_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
             "qcat_ctx_destroy": (None, [vp]),
@@ -262,12 +263,17 @@ class HipLibrary(object):
 class NativeKit(object):
     """``qcat_kit*`` handle (immutable, shareable)."""
 
-    def __init__(self, descriptor):
+    def __init__(self, descriptor, jit=None):
+        """``jit``: compile static-letter kernels for templates / barcode sets that are not in the
+        built-in bundle (qcat_amd.jit); None = follow the QCAT_AMD_JIT environment switch."""
         self.hip = HipLibrary.get()
         self.descriptor = descriptor
         h = C.c_void_p()
         self.hip.check(self.hip.lib.qcat_kit_create(descriptor.byref(), C.byref(h)))
         self.handle = h
+        from . import jit as jit_mod
+        if jit or (jit is None and jit_mod.enabled()):
+            jit_mod.attach(self)
 
     def describe(self):
         """dict of qcat_kit_info: packed / fp16 eligibility and how many templates and barcode groups
