@@ -14,6 +14,7 @@ text, of that file; all alignment work happens in one native call per batch.
 from __future__ import print_function
 
 import argparse
+import itertools
 import logging
 import os
 import sys
@@ -105,16 +106,17 @@ def is_fastq(filename):
 def _fastq_records(handle):
     """4-line FASTQ records -> (title, seq, qual).  (The reference delegates to Biopython's
     FastqGeneralIterator, which also accepts wrapped records; ONT FASTQ is 4-line.)"""
-    while True:
-        head = handle.readline()
-        if not head:
-            return
-        if not head.startswith("@"):
+    lines = iter(handle)
+    for head, seq, plus, qual in itertools.zip_longest(lines, lines, lines, lines):   # four lines per step
+        if qual is None:
+            if head.strip() == "" and seq is None:
+                return                                      # trailing blank line
+            raise ValueError("Malformed FASTQ record: " + head.strip())
+        if head[0] != "@":
             raise ValueError("Records in Fastq files should start with '@' character")
-        seq = handle.readline().rstrip("\n")
-        plus = handle.readline()
-        qual = handle.readline().rstrip("\n")
-        if not plus.startswith("+") or len(qual) != len(seq):
+        seq = seq.rstrip("\n")
+        qual = qual.rstrip("\n")
+        if plus[0] != "+" or len(qual) != len(seq):
             raise ValueError("Malformed FASTQ record: " + head.strip())
         yield head[1:].rstrip("\n"), seq, qual
 

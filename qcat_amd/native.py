@@ -179,8 +179,20 @@ class KitInfo(C.Structure):
 
 def pack_reads(read_sequences):
     """list of str/bytes/None -> (uint8 bases, uint64 offsets[n+1])."""
+    n = len(read_sequences)
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    if n and all(type(s) is str for s in read_sequences):
+        # the common case (FASTQ batches): one join + one encode instead of one per read
+        joined = "".join(read_sequences)
+        try:
+            raw = joined.encode("ascii")
+        except UnicodeEncodeError:
+            raw = None                                    # non-ASCII characters: per-read path below
+        if raw is not None:
+            np.cumsum(np.fromiter(map(len, read_sequences), dtype=np.uint64, count=n), out=offsets[1:])
+            bases = np.frombuffer(raw, dtype=np.uint8) if raw else np.zeros(1, dtype=np.uint8)
+            return np.ascontiguousarray(bases), offsets
     chunks = []
-    offsets = np.zeros(len(read_sequences) + 1, dtype=np.uint64)
     total = 0
     for i, s in enumerate(read_sequences):
         if s:

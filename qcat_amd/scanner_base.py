@@ -119,6 +119,41 @@ class BarcodeScanner(object):
                                  int(rec["exit_status"]), trim5p=int(rec["trim5p"]),
                                  trim3p=int(rec["trim3p"]))
 
+    def _records_to_dicts(self, recs, layouts):
+        """vectorised ``_record_to_dict``: plain Python ints per column instead of one numpy record
+        access per field and read (the host side of a batch is otherwise dominated by this loop)"""
+        bidx = recs["barcode_idx"].tolist()
+        b2idx = recs["barcode2_idx"].tolist()
+        aidx = recs["adapter_idx"].tolist()
+        aend = recs["adapter_end"].tolist()
+        status = recs["exit_status"].tolist()
+        t5 = recs["trim5p"].tolist()
+        t3 = recs["trim3p"].tolist()
+        # the same IEEE double expression as scanner_base.py:119: raw * 100.0 / (1.0 * den)
+        den = np.maximum(recs["score_den"].astype(np.float64), 1.0)
+        score = (recs["raw_score"].astype(np.float64) * 100.0 / (1.0 * den)).tolist()
+        sets0 = [lay.get_barcode_set(0) if lay.barcode_set_1 is not None else None for lay in layouts]
+        sets1 = [lay.get_barcode_set(1) if getattr(lay, "barcode_set_2", None) else None for lay in layouts]
+        out = []
+        for i in range(len(bidx)):
+            a = aidx[i]
+            adapter = layouts[a] if a >= 0 else None
+            barcode, sc = None, 0.0
+            b = bidx[i]
+            if b >= 0:
+                first = sets0[a][b]
+                b2 = b2idx[i]
+                if b2 >= 0:
+                    second = sets1[a][b2]
+                    barcode = Barcode("barcode{:02d}/{:02d}".format(first.id, second.id),
+                                      "{}/{}".format(first.id, second.id), None, True)
+                else:
+                    barcode = first
+                sc = score[i]
+            out.append({"barcode": barcode, "barcode_score": sc, "adapter": adapter, "adapter_end": aend[i],
+                        "trim5p": t5[i], "trim3p": t3[i], "exit_status": status[i]})
+        return out
+
     def _run(self, read_sequences, layouts, qcat_config, ends=native.ENDS_BOTH):
         if not layouts:
             # the reference indexes an empty template list here (IndexError)
@@ -126,7 +161,7 @@ class BarcodeScanner(object):
         kit = self._native_kit(layouts, qcat_config, ends)
         bases, offsets = native.pack_reads(read_sequences)
         recs = self._context().scan(kit, bases, offsets)
-        return [self._record_to_dict(r, layouts) for r in recs]
+        return self._records_to_dicts(recs, layouts)
 
     # -- reference API ----------------------------------------------------------------------------
     def scan(self, read_sequence, read_qualities, barcoding_kits, non_barocding_kits,
