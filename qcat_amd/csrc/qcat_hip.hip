@@ -13,6 +13,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kit.h"
@@ -221,6 +222,7 @@ struct qcat_batch {
     uint8_t* bases = nullptr;      // bases_alloc + BATCH_SLACK: k_pack_windows reads whole aligned dwords
                                    // up to 19 bytes before / after a read's window
     uint64_t* offsets = nullptr;   // n_reads + 1
+    uint32_t* true_len = nullptr;  // window-only batches (batch_upload_windows): the reads' real lengths
 };
 
 // ------------------------------------------------------------------------------------------
@@ -238,6 +240,9 @@ struct qcat_ctx {
     EndRec* recs = nullptr;
     qcat_result* results = nullptr;
     unsigned long long* counts = nullptr;
+    // pinned staging of window-only uploads (qcat_scan_batch): compact bases, offsets, real lengths
+    uint8_t* pin_bases = nullptr; size_t cap_pin_bases = 0;
+    uint64_t* pin_offsets = nullptr; uint32_t* pin_len = nullptr; size_t cap_pin_reads = 0;
     PackedScratch packed;
     // packed --detect-middle (kernels_middle.inc): M-end sort tables and per-slot arrays
     MidTables* mid_tables = nullptr;
@@ -288,6 +293,9 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->recs); (void)hipFree(c->results);
     (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows);
     packed_scratch_free(&c->packed);
+    if (c->pin_bases) (void)hipHostFree(c->pin_bases);
+    if (c->pin_offsets) (void)hipHostFree(c->pin_offsets);
+    if (c->pin_len) (void)hipHostFree(c->pin_len);
     (void)hipFree(c->mid_tables); (void)hipFree(c->mid_generic); (void)hipFree(c->mid_slot); (void)hipFree(c->mid_sorted);
     (void)hipFree(c->mid_len); (void)hipFree(c->mid_fallback); (void)hipFree(c->mid_recs); (void)hipFree(c->mid_bests);
     if (c->ev_ready) for (int r = 0; r < qcat_ctx::TIME_RING; ++r) for (int i = 0; i <= MAX_TIMED; ++i) (void)hipEventDestroy(c->evr[r][i]);
@@ -460,7 +468,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, hk.n_buckets > 2048 ? 512 : 4096);
         const bool middle = hk.scan_middle != 0;
         hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, c->stream,
-                           kp, c->recs, b->offsets, n, c->results, middle ? nullptr : c->counts);
+                           kp, c->recs, b->offsets, b->true_len, n, c->results, middle ? nullptr : c->counts);
         mark(c, "k_finalize");
         if (middle) {
             const uint8_t* only = nullptr;
@@ -543,7 +551,7 @@ extern "C" void qcat_batch_destroy(qcat_batch* b) {
     if (!b) return;
     int cur = 0; (void)hipGetDevice(&cur);
     (void)hipSetDevice(b->device);
-    (void)hipFree(b->bases_alloc); (void)hipFree(b->offsets);
+    (void)hipFree(b->bases_alloc); (void)hipFree(b->offsets); (void)hipFree(b->true_len);
     (void)hipSetDevice(cur);
     delete b;
 }
@@ -572,6 +580,82 @@ extern "C" int qcat_batch_upload(qcat_ctx* c, const uint8_t* bases, const uint64
     if (b->n_bases) HIPCHK(hipMemcpyAsync(b->bases, bases, b->n_bases, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b->offsets, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    *out = b;
+    return 0;
+}
+
+// Host-buffer entry points scan only the first / last max_align_length bases of a read, so that is
+// all they send over PCIe: every read is compacted to head + tail (reads up to 2n stay whole, which
+// keeps the two windows byte-identical), the real length travels in a separate array for the trims.
+// The compaction runs on a few host threads into pinned memory.  --detect-middle needs whole reads.
+static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t* bases, const uint64_t* offsets,
+                                uint32_t n_reads, qcat_batch** out) {
+    const DevKit& hk = kit->hk.dk;
+    if (hk.scan_middle || n_reads < 4096 || getenv("QCAT_HIP_FULL_UPLOAD"))
+        return qcat_batch_upload(c, bases, offsets, n_reads, out);
+    if (!c || !offsets || !out || (!bases && offsets[n_reads] > 0)) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
+    if (offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t n = (uint64_t)hk.max_align;
+    const bool both = hk.ends == QCAT_ENDS_BOTH;
+    const uint64_t keep = both ? 2 * n : n;
+    if ((size_t)n_reads + 1 > c->cap_pin_reads) {
+        if (c->pin_offsets) (void)hipHostFree(c->pin_offsets);
+        if (c->pin_len) (void)hipHostFree(c->pin_len);
+        c->pin_offsets = nullptr; c->pin_len = nullptr; c->cap_pin_reads = 0;
+        HIPCHK(hipHostMalloc((void**)&c->pin_offsets, ((size_t)n_reads + 1) * 8));
+        HIPCHK(hipHostMalloc((void**)&c->pin_len, ((size_t)n_reads + 1) * 4));
+        c->cap_pin_reads = (size_t)n_reads + 1;
+    }
+    uint64_t total = 0;
+    c->pin_offsets[0] = 0;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        if (offsets[r + 1] < offsets[r]) return set_err(QCAT_ERR_ARG, "offsets must be non-decreasing");
+        const uint64_t len = offsets[r + 1] - offsets[r];
+        if (len > 0xFFFFFFFFull) return set_err(QCAT_ERR_UNSUPPORTED, "read longer than 4 Gb");
+        c->pin_len[r] = (uint32_t)len;
+        total += len <= keep ? len : keep;
+        c->pin_offsets[r + 1] = total;
+    }
+    if (total + 1 > c->cap_pin_bases) {
+        if (c->pin_bases) (void)hipHostFree(c->pin_bases);
+        c->pin_bases = nullptr; c->cap_pin_bases = 0;
+        HIPCHK(hipHostMalloc((void**)&c->pin_bases, total + 1));
+        c->cap_pin_bases = total + 1;
+    }
+    {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nthreads = std::min<unsigned>(std::min(hw, 16u), std::max<uint32_t>(1u, n_reads / 16384u));
+        auto work = [&](uint32_t r0, uint32_t r1) {
+            for (uint32_t r = r0; r < r1; ++r) {
+                const uint8_t* src = bases + offsets[r];
+                const uint64_t len = offsets[r + 1] - offsets[r];
+                uint8_t* dst = c->pin_bases + c->pin_offsets[r];
+                if (len <= keep) { memcpy(dst, src, len); continue; }
+                memcpy(dst, src, n);
+                if (both) memcpy(dst + n, src + len - n, n);
+            }
+        };
+        std::vector<std::thread> pool;
+        const uint32_t per = (n_reads + nthreads - 1) / nthreads;
+        for (unsigned t = 1; t < nthreads; ++t) {
+            const uint32_t r0 = std::min<uint32_t>(n_reads, t * per), r1 = std::min<uint32_t>(n_reads, r0 + per);
+            if (r0 < r1) pool.emplace_back(work, r0, r1);
+        }
+        work(0, std::min<uint32_t>(n_reads, per));
+        for (auto& th : pool) th.join();
+    }
+    qcat_batch* b = new qcat_batch();
+    b->device = c->device; b->n_reads = n_reads; b->n_bases = total;
+    hipError_t e1 = hipMalloc((void**)&b->bases_alloc, total + 2 * BATCH_SLACK);
+    if (e1 == hipSuccess) b->bases = b->bases_alloc + BATCH_SLACK;
+    hipError_t e2 = hipMalloc((void**)&b->offsets, ((size_t)n_reads + 1) * 8);
+    hipError_t e3 = hipMalloc((void**)&b->true_len, ((size_t)n_reads + 1) * 4);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { qcat_batch_destroy(b); return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch"); }
+    if (total) HIPCHK(hipMemcpyAsync(b->bases, c->pin_bases, total, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(b->offsets, c->pin_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(b->true_len, c->pin_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));           // the pinned staging is reused by the next call
     *out = b;
     return 0;
 }
@@ -719,7 +803,7 @@ extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
         if ((int)row_stride < need) return set_err(QCAT_ERR_ARG, "row_stride smaller than the largest barcode set");
     }
     qcat_batch* b = nullptr;
-    int rc = qcat_batch_upload(c, bases, offsets, n_reads, &b);
+    int rc = batch_upload_windows(c, kit, bases, offsets, n_reads, &b);
     if (rc) return rc;
     const bool debug = traces != nullptr || bc_rows != nullptr;
     rc = scan_resident_impl(c, kit, b, debug, bc_rows ? row_stride : 0);
@@ -754,7 +838,7 @@ extern "C" int qcat_detect_kit(qcat_ctx* c, const qcat_kit* ckit, const uint8_t*
     const int nt = kit->hk.dk.nt;
     std::vector<unsigned long long> hv(MAX_T, 0), hf(MAX_T, ~0ull);
     qcat_batch* b = nullptr;
-    int rc = qcat_batch_upload(c, bases, offsets, n_reads, &b);
+    int rc = batch_upload_windows(c, kit, bases, offsets, n_reads, &b);
     if (rc) return rc;
     rc = scan_resident_impl(c, kit, b, false, 0, true);
     DevTemp vote_buf;

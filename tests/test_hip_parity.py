@@ -264,3 +264,16 @@ def test_empty_batch_and_api_misuse():
     # fetching results of a different batch size than the last scan is an error
     out3 = np.zeros(3, dtype=native.RESULT_DTYPE)
     assert hip.lib.qcat_ctx_fetch_results(ctx().handle, out3.ctypes.data, 3) == -1
+
+
+def test_host_buffer_scan_uploads_windows_only():
+    """qcat_scan_batch compacts every read to head + tail on the host (batches >= 4096 reads): same
+    records, traces and counts as the oracle, for both end modes, with reads around the 150 / 300-nt
+    boundaries where head and tail overlap."""
+    det = scanner.factory(kit="NBD103/NBD104")
+    reads = synth.synth_batch(4400, 2024, det.layouts, 1, 0, error_rate=0.08)
+    for i, cut in enumerate((0, 1, 149, 150, 151, 299, 300, 301, 302, 449, 450, 451)):
+        reads[i] = reads[100 + i][:cut]
+    for ends in (native.ENDS_BOTH, native.ENDS_5P):
+        d, recs, traces, rows, cnt = hip_scan(det, reads, ends=ends)
+        assert_same_as_oracle(d, reads, recs, traces, rows, cnt)
