@@ -296,9 +296,15 @@ def main():
                     cells_b += len(bs) * int(t["region_len"][s]) * tlen
             cells_a /= float(probe)
             cells_b /= float(probe)
+            region_frac = float(np.mean([int(t["region_path"]) for t in tr1])) if len(tr1) else 0.0
+            try:
+                with open("/proc/cpuinfo") as fh:
+                    cpu_model = [l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")][0]
+            except (IOError, IndexError):
+                cpu_model = "unknown CPU"
             out["cpu_baseline"] = {"value": round(all_cores, 1), "unit": "reads/s", "cores": ncpu, "kind": "port",
                                    "sample": "first %d reads of rank 0's shard, oracle/qcat_oracle.c with OpenMP over "
-                                             "%d threads (1 thread: %.0f reads/s on %d reads)" % (n_sample, ncpu, one_thread, probe)}
+                                             "%d threads of %s (1 thread: %.0f reads/s on %d reads)" % (n_sample, ncpu, cpu_model, one_thread, probe)}
             out["parity"] = {"checked_reads": n_sample, "mismatches_vs_oracle": mism}
             # VALU-issue ceilings: one wave retires 128 cells per column; cycles per column from the issue
             # rates tools/valu_rate.hip measures on this chip (profiles/r01_valu_issue_rates.txt)
@@ -307,7 +313,8 @@ def main():
                    "k_barcode_packed": 4.17 + 4.18 + 4.20,           # v_perm_b32 + v_pk_add_f16 + v_pk_maximum3_f16
                    "k_adapter_static": 4.18 + 4.20,                  # v_pk_add_f16 + v_pk_maximum3_f16 (static letters)
                    "k_barcode_static": 4.18 + 4.20}
-            valu = {"unit": "DP cell updates/s", "dp_cells_per_read": round(cells_a + cells_b, 1)}
+            valu = {"unit": "DP cell updates/s", "dp_cells_per_read": round(cells_a + cells_b, 1),
+                    "region_path_fraction": round(region_frac, 4)}
             ideal_s = 0.0
             for name, cells, kerns in (("adapter", cells_a, ("k_adapter_static", "k_adapter_packed")),
                                        ("barcode", cells_b, ("k_barcode_static", "k_barcode_packed"))):
