@@ -231,7 +231,7 @@ def main():
                "counts_total": int(total_counts[: n_buckets - len(desc.kit_names) - 1].sum()),
                "count_allreduce": ("rccl in place on the device vector" if state["zero_copy"] else
                                    ("rccl via host staging" if use_dist else "single process"))}
-        if not a.no_host_inclusive:
+        if not a.no_host_inclusive and world == 1:
             # PCIe-inclusive rate of the host-buffer entry point (never `value`): download the shard,
             # then time qcat_scan_batch (upload + scan + 24 B/read download) twice, keep the faster.
             hb = np.zeros(nb.value, dtype=np.uint8)
@@ -252,7 +252,7 @@ def main():
                                              "%.0f MB down per step" % (nb.value / 1e6, up / 1e6, a.reads * 24 / 1e6)}
 
         # ---- CPU baseline + parity on a bounded sample of rank 0's shard ---------------------
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # the CPU legs run on rank 0 at N = 1 only
             import oracle_lib
             ncpu = usable_cores()
 
@@ -333,6 +333,8 @@ def main():
                             "v_pk_add_f16 + v_pk_maximum3_f16 = 8.38 cycles; table kernels 12.55 (fp16 lanes) / 15.2 (u16 lanes); "
                             "frac_of_valu_peak = ideal DP time of both phases / whole step time")
             out["valu"] = valu
+        if world > 1:
+            out.setdefault("cpu_baseline", None)        # measured at N = 1 (the driver's first run)
         print(json.dumps(out))
         sys.stdout.flush()
     lib.qcat_batch_destroy(batch)
