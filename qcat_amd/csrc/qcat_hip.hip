@@ -23,6 +23,7 @@
 #include "kernels_common.inc"
 #include "kernels_generic.inc"
 #include "kernels_packed.inc"
+#include "packed_host.inc"
 #include "kernels_static.inc"
 #include "kernels_middle.inc"
 #include "static_registry.inc"
