@@ -86,16 +86,27 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
             m = len(targets[0])
             if any(len(x) != m or any(c > 3 for c in x) for x in targets) or not 1 <= m <= 64:
                 continue
-            for b, tg in enumerate(targets):
-                parts.append("struct QSCJ_%d_%d { static __device__ __forceinline__ void run(h2 (&h)[%d], h2& carry, h2& left, "
-                             "const h2 (&E)[4]) { %s } };\n" % (g, b, m + 1, _chain(tg)))
+            u = len(up)
+            pre = _chain(targets[0][:u]) if u else ""
+            npairs = (len(targets) + 1) // 2
+            for pr in range(npairs):
+                ta = targets[2 * pr]
+                tb = targets[min(2 * pr + 1, len(targets) - 1)]      # an odd last target is paired with itself
+                parts.append("struct QSPJ_%d_%d {\n" % (g, pr))
+                parts.append("    static __device__ __forceinline__ void pre(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
+                             % (u + 1, pre))
+                for name, tg in (("ta", ta), ("tb", tb)):
+                    parts.append("    static __device__ __forceinline__ void %s(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
+                                 % (name, m - u + 1, _chain(tg[u:])))
+                parts.append("};\n")
             parts.append("struct QSGJ_%d {\n    static constexpr int M = %d;\n"
-                         "    static __device__ __forceinline__ u32 run(int kc, const uint8_t* qbuf, int lane, int Lmax, h2 gL2, "
-                         "u32 special, const u32 (&ltr)[4], h2 rowoff, h2 coloff) {\n        switch (kc) {\n" % (g, m))
-            for b in range(len(targets)):
-                parts.append("        case %d: return static_barcode_rows<M, QSCJ_%d_%d>(qbuf, lane, Lmax, gL2, special, ltr, rowoff, coloff);\n"
-                             % (b, g, b))
-            parts.append("        default: return 0;\n        }\n    }\n};\n")
+                         "    static __device__ __forceinline__ void run(int pair, const uint8_t* qbuf, int lane, int Lmax, h2 gL2, "
+                         "u32 special, const u32 (&ltr)[4], h2 rowoff, h2 coloff, u32& ra, u32& rb) {\n        ra = 0; rb = 0;\n"
+                         "        switch (pair) {\n" % (g, m))
+            for pr in range(npairs):
+                parts.append("        case %d: static_barcode_rows2<M, %d, QSPJ_%d_%d>(qbuf, lane, Lmax, gL2, special, ltr, rowoff, coloff, ra, rb); break;\n"
+                             % (pr, u, g, pr))
+            parts.append("        default: break;\n        }\n    }\n};\n")
             entry.append('extern "C" __global__ void __launch_bounds__(qk::PK_WAVES * 64, 4) '
                          "qj_bc_%d(qk::StaticArgs a) { qk::barcode_static_body<qk::QSGJ_%d>(a); }\n" % (g, g))
             grp_flags[g] = 1
