@@ -331,7 +331,9 @@ def main():
             valu["note"] = ("ceiling = 1024 SIMDs x 2.4 GHz x 128 cells per wave-column / VALU issue cycles per column "
                             "(issue rates measured by tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt): static-letter kernels "
                             "v_pk_add_f16 + v_pk_maximum3_f16 = 8.38 cycles; table kernels 12.55 (fp16 lanes) / 15.2 (u16 lanes); "
-                            "frac_of_valu_peak = ideal DP time of both phases / whole step time")
+                            "frac_of_valu_peak = ideal DP time of both phases / whole step time.  Cells are the "
+                            "reference-defined ones (SURVEY.md 8d); the barcode chains run two targets per row pass and "
+                            "compute their shared upstream-flank columns once, so `barcode.frac` can exceed 1")
             out["valu"] = valu
         if world > 1:
             out.setdefault("cpu_baseline", None)        # measured at N = 1 (the driver's first run)
