@@ -277,3 +277,30 @@ def test_host_buffer_scan_uploads_windows_only():
     for ends in (native.ENDS_BOTH, native.ENDS_5P):
         d, recs, traces, rows, cnt = hip_scan(det, reads, ends=ends)
         assert_same_as_oracle(d, reads, recs, traces, rows, cnt)
+
+
+def test_timing_ring_and_stream_accessor():
+    """qcat_ctx_last_timing averages over the scans since the previous call (no sync between scans);
+    qcat_ctx_stream hands out the context's stream for stream-ordered RCCL calls."""
+    hip = native.HipLibrary.get()
+    lib = hip.lib
+    c = native.NativeContext(0)
+    assert lib.qcat_ctx_stream(c.handle)
+    det = scanner.factory(kit="NBD103/NBD104")
+    kit = native.NativeKit(det.descriptor(ends=native.ENDS_5P))
+    sp = native.SynthParams(seed=3, n_reads=20000, insert_len=600, lead_min=5, lead_max=40, error_rate=0.08,
+                            no_adapter_fraction=0.05, tpl_5p=1, tpl_3p=0)
+    b = C.c_void_p()
+    hip.check(lib.qcat_batch_synthesize(c.handle, kit.handle, C.byref(sp), C.byref(b)))
+    names = (C.c_char_p * 16)()
+    ms = (C.c_float * 16)()
+    assert lib.qcat_ctx_last_timing(c.handle, names, ms, 16) == 0          # timing is off by default
+    hip.check(lib.qcat_ctx_set_timing(c.handle, 1))
+    for _ in range(70):                                                  # more scans than the ring holds
+        hip.check(lib.qcat_scan_resident(c.handle, kit.handle, b))
+    k = lib.qcat_ctx_last_timing(c.handle, names, ms, 16)
+    got = [names[i].decode() for i in range(k)]
+    assert got[0] == "k_pack_windows" and got[-1] == "k_finalize" and "k_barcode_static" in got
+    assert all(0.0 < ms[i] < 50.0 for i in range(k))
+    assert lib.qcat_ctx_last_timing(c.handle, names, ms, 16) == 0          # drained
+    lib.qcat_batch_destroy(b)
