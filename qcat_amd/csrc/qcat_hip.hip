@@ -639,11 +639,16 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
         };
         std::vector<std::thread> pool;
         const uint32_t per = (n_reads + nthreads - 1) / nthreads;
+        uint32_t done_to = std::min<uint32_t>(n_reads, per);          // [0, per) is this thread's share
         for (unsigned t = 1; t < nthreads; ++t) {
             const uint32_t r0 = std::min<uint32_t>(n_reads, t * per), r1 = std::min<uint32_t>(n_reads, r0 + per);
-            if (r0 < r1) pool.emplace_back(work, r0, r1);
+            if (r0 >= r1) break;
+            try { pool.emplace_back(work, r0, r1); }
+            catch (const std::exception&) { break; }                 // no more threads: the rest runs here
+            done_to = r1;
         }
         work(0, std::min<uint32_t>(n_reads, per));
+        if (done_to < n_reads) work(done_to, n_reads);
         for (auto& th : pool) th.join();
     }
     qcat_batch* b = new qcat_batch();
