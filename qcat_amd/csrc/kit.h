@@ -77,6 +77,7 @@ struct DevKit {
     uint32_t adapter_pool_lo[5], adapter_pool_hi[5];
     uint16_t adapter_w16[5 * 8];
     int32_t adapter_f16;        // the binary16 adapter DP is exact for this kit (static adapter kernels allowed)
+    int32_t adapter_f16_headroom;   // 2047 - (largest value the window-sized biased adapter DP can reach)
     int8_t amat[49], bmat[49];
     int8_t pad_[2];
     DevTpl tpl[MAX_T];

@@ -339,6 +339,9 @@ static void mark(qcat_ctx* c, const char* name) {
 // kernel (all built-in kits) and the kit's slots fit the sort tables
 static bool middle_packed_ok(const DevKit& hk) {
     if (!hk.adapter_f16 || hk.n_kit_slots > MID_MAX_KITS || getenv("QCAT_HIP_MIDDLE_GENERIC")) return false;
+    // the interior kernel carries up to PK_ROWS + 63 rows of bias inside a block plus the offset of its
+    // last-row keys (kernels_middle.inc): g * ((152 + 63 + 128 + 64) - (160 + 128)) + 1 more than a window
+    if (hk.adapter_f16_headroom < hk.gap_open * 119 + 1) return false;
     for (int t = 0; t < hk.nt; ++t) if (hk.tpl[t].static_kernel < 0) return false;
     return true;
 }
