@@ -217,3 +217,28 @@ def test_packed_detect_middle_matches_generic_kernel_and_oracle(monkeypatch, mod
     assert recs.tobytes() == o_recs.tobytes()
     assert np.array_equal(cnt, o_cnt)
     assert (recs["exit_status"] == 997).sum() > 20
+
+
+@gpu
+@pytest.mark.parametrize("match,mismatch,gap", [(4, -3, 1), (6, -1, 3), (9, -4, 4)])
+def test_packed_detect_middle_with_custom_scoring(match, mismatch, gap):
+    """non-default adapter scoring: the static kernels take their scores from the kit at run time; where
+    the binary16 bound does not hold (last case) the table / general kernels run -- same answers"""
+    from qcat_amd import config
+    cfg = config.qcatConfig()
+    cfg.match, cfg.mismatch = match, mismatch
+    cfg.gap_open = cfg.gap_extend = gap
+    cfg.update_matrix()
+    det = scanner.factory(kit="PBK004/LWB001", scan_middle_adapter=True)
+    base = synth.synth_batch(240, 808, det.layouts, 1, 0, error_rate=0.07)
+    reads = [r + r if i % 2 == 0 else r for i, r in enumerate(base)] + ["", "ACGT" * 90]
+    d = det.descriptor(qcat_config=cfg)
+    kit_h = native.NativeKit(d)
+    info = kit_h.describe()
+    assert info["adapter_f16"] == (1 if (match + 2 * gap) * 128 + gap * 288 <= 2047 else 0)
+    bases, offsets = native.pack_reads(reads)
+    cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+    recs = ctx().scan(kit_h, bases, offsets, counts=cnt)
+    o_recs, o_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
+    assert recs.tobytes() == o_recs.tobytes()
+    assert np.array_equal(cnt, o_cnt)
