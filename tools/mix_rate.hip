@@ -1,4 +1,4 @@
-// mix_rate.hip -- what does one DP column cost?  Compares the two candidate instruction mixes for the
+// mix_rate.hip -- what does one DP column cost?  Compares the candidate instruction mixes (A-H) for the
 // score lookup of the packed kernels at 4 waves/SIMD:
 //   A: v_perm_b32 + v_add_u32 + 2 x v_pk_max_u16                (all VALU)
 //   B: ds_bpermute_b32 (LDS crossbar) + v_add_u32 + 2 x v_pk_max_u16
