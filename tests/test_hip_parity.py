@@ -304,3 +304,32 @@ def test_timing_ring_and_stream_accessor():
     assert all(0.0 < ms[i] < 50.0 for i in range(k))
     assert lib.qcat_ctx_last_timing(c.handle, names, ms, 16) == 0          # drained
     lib.qcat_batch_destroy(b)
+
+
+def test_one_kit_shared_by_concurrent_contexts():
+    """a qcat_kit is immutable and shareable, a qcat_ctx belongs to one host thread: four threads scan
+    different batches through their own contexts with the SAME kit handle (ctypes drops the GIL)."""
+    import threading
+    det = scanner.factory(kit="PBC096")
+    d = det.descriptor()
+    kit = native.NativeKit(d)
+    batches = [synth.synth_batch(1500, 100 + i, det.layouts, 1, 0, error_rate=0.08) for i in range(4)]
+    want = [oracle_lib.scan(d, b, threads=4).tobytes() for b in batches]
+    got, errors = [None] * 4, []
+
+    def work(i):
+        try:
+            c = native.NativeContext(0)
+            bases, offsets = native.pack_reads(batches[i])
+            for _ in range(3):
+                got[i] = c.scan(kit, bases, offsets).tobytes()
+        except Exception as exc:                      # pragma: no cover - reported below
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert got == want
