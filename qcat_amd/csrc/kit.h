@@ -59,6 +59,8 @@ struct DevTpl {
     int32_t tbl_off;            // tables blob: `width` dwords, right-aligned (-1: not eligible)
     int32_t width;              // register-array width class of the packed adapter kernel
     int32_t static_kernel;      // generated static-letter adapter kernel (kernels_static.inc), -1: none
+    int32_t fused_kernel;       // generated kernel that scans this template AND `fused_partner` in one pass, -1: none
+    int32_t fused_partner;
     DevSet sets[2];
 };
 

@@ -95,7 +95,7 @@ def same(a, b):
 
 VARIANTS = [{"QCAT_HIP_NO_STATIC": "1"}, {"QCAT_HIP_NO_STATIC_ADAPTER": "1"}, {"QCAT_HIP_ONE_STREAM": "1"},
             {"QCAT_HIP_NO_STATIC": "1", "QCAT_HIP_BARCODE_U16": "1"}, {"QCAT_HIP_CHUNK_BARCODES": "1"},
-            {"QCAT_HIP_CHUNK_BARCODES": "1000"}, {"QCAT_HIP_ONE_QUEUE": "1"}]
+            {"QCAT_HIP_CHUNK_BARCODES": "1000"}, {"QCAT_HIP_ONE_QUEUE": "1"}, {"QCAT_HIP_NO_FUSED_ADAPTER": "1"}]
 
 
 @gpu
