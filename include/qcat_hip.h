@@ -188,11 +188,15 @@ int  qcat_kit_describe(const qcat_kit* kit, qcat_kit_info* out);
  * is a gfx950 code object (hipcc --genco of the translation unit qcat_amd/jit.py generates from
  * qcat_amd/csrc/jit_prelude.inc plus the kit's column chains) exporting qj_ad_<t> / qj_am_<t> for every
  * template t with template_flags[t] != 0 and qj_bc_<t*2+s> for every (template, set) group with
- * group_flags[t*2+s] != 0 (arrays of QCAT_MAX_TEMPLATES and 2*QCAT_MAX_TEMPLATES entries).  Must be
+ * group_flags[t*2+s] != 0 (arrays of QCAT_MAX_TEMPLATES and 2*QCAT_MAX_TEMPLATES entries).  The barcode
+ * chains run two targets per row pass: pair_entries holds, for group g, the triples
+ * (pair case in qj_bc_<g>, kit barcode of half 0 or -1, kit barcode of half 1 or -1) at
+ * [pair_offsets[g], pair_offsets[g+1]) (pair_offsets has 2*QCAT_MAX_TEMPLATES + 1 entries).  Must be
  * called before the kit is first used on a device; templates / groups already bound to built-in
  * generated kernels keep those. */
 int  qcat_kit_attach_code(qcat_kit* kit, const void* code, uint64_t size,
-                          const int32_t* template_flags, const int32_t* group_flags);
+                          const int32_t* template_flags, const int32_t* group_flags,
+                          const int32_t* pair_offsets, const int32_t* pair_entries);
 
 int  qcat_ctx_create(int device, qcat_ctx** out);
 void qcat_ctx_destroy(qcat_ctx* ctx);

@@ -48,7 +48,8 @@ struct DevSet {
     int32_t min_raw_conflict;   // smallest raw with raw*100.0/tlen >= conflict_min_score
     int32_t min_raw_middle;     // smallest raw with raw*100.0/tlen >= middle_min_score (--detect-middle)
     int32_t static_kernel;      // generated static-letter kernel of this group (kernels_static.inc), -1: none
-    int32_t case_off;           // ids blob: n case indices into that kernel
+    int32_t case_off;           // ids blob: n_pairs entries (pair case, barcode of half 0 or -1, barcode of half 1 or -1)
+    int32_t n_pairs;            // target pairs the static kernel runs for this group
 };
 
 struct DevTpl {

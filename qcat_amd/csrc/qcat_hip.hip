@@ -113,8 +113,10 @@ extern "C" int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {
 }
 
 extern "C" int qcat_kit_attach_code(qcat_kit* k, const void* code, uint64_t size,
-                                    const int32_t* template_flags, const int32_t* group_flags) {
-    if (!k || !code || !size || !template_flags || !group_flags) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: null argument");
+                                    const int32_t* template_flags, const int32_t* group_flags,
+                                    const int32_t* pair_offsets, const int32_t* pair_entries) {
+    if (!k || !code || !size || !template_flags || !group_flags || !pair_offsets || !pair_entries)
+        return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: null argument");
     std::lock_guard<std::mutex> lock(k->mu);
     for (int d = 0; d < MAX_DEVICES; ++d)
         if (k->dev[d].ready) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: the kit is already in use on a device");
@@ -128,9 +130,13 @@ extern "C" int qcat_kit_attach_code(qcat_kit* k, const void* code, uint64_t size
         for (int s = 0; s < nsets; ++s) {
             DevSet& q = d.tpl[t].sets[s];
             if (!group_flags[t * 2 + s] || !d.barcode_f16 || q.static_kernel >= 0 || q.n <= 0) continue;
+            const int32_t* ent = pair_entries + pair_offsets[t * 2 + s] * 3;
+            const int np = pair_offsets[t * 2 + s + 1] - pair_offsets[t * 2 + s];
+            if (np <= 0) continue;
             q.static_kernel = QCAT_JIT_BASE + t * 2 + s;
-            q.case_off = (int32_t)h.ids.size();          // generated for exactly this kit: case b = barcode b
-            for (int b = 0; b < q.n; ++b) h.ids.push_back(b);
+            q.n_pairs = np;
+            q.case_off = (int32_t)h.ids.size();          // (pair case, barcode of half 0, barcode of half 1) per pair
+            h.ids.insert(h.ids.end(), ent, ent + (size_t)np * 3);
             k->jit_grp[t * 2 + s] = true;
         }
     }

@@ -56,15 +56,41 @@ def _chain(codes):
     return " ".join(out)
 
 
+def _lcp(a, b):
+    n = 0
+    while n < len(a) and n < len(b) and a[n] == b[n]:
+        n += 1
+    return n
+
+
+def _pair_up(targets, flank):
+    """greedy pairing of the set's targets by longest common prefix (two targets run in one row pass
+    and share their common prefix columns): [(barcode a, barcode b or -1, shared columns)]"""
+    idx = range(len(targets))
+    cand = sorted(((-_lcp(targets[i], targets[j]), i, j) for i in idx for j in idx if i < j))
+    used, pairs = set(), []
+    for neg, i, j in cand:
+        if i in used or j in used or targets[i] == targets[j]:
+            continue
+        used.update((i, j))
+        pairs.append((i, j, min(-neg, len(targets[i]) - 1)))
+    for i in idx:
+        if i not in used:
+            pairs.append((i, -1, flank))
+    return sorted(pairs)
+
+
 def generate(descriptor, skip_templates=(), skip_groups=()):
-    """(source text, template flags, group flags) for the templates / (template, set) groups of
-    ``descriptor`` that can take static-letter kernels and are not in the skip lists"""
+    """(source text, template flags, group flags, pair entries per group) for the templates /
+    (template, set) groups of ``descriptor`` that can take static-letter kernels and are not in the
+    skip lists"""
     n = int(descriptor.desc.barcode_context_length)
     nsets = 2 if descriptor.mode == "dual" else 1
     tpl_flags = [0] * MAX_TEMPLATES
     grp_flags = [0] * (2 * MAX_TEMPLATES)
     parts = ['#include "jit_prelude.inc"\n', "namespace qk {\n"]
     entry = []
+    entries = [[] for _ in range(2 * MAX_TEMPLATES)]          # per group: (pair case, barcode a, barcode b or -1)
     for t, lay in enumerate(descriptor.layouts):
         tcodes = _codes(lay.sequence)
         if t not in skip_templates and all(c <= 4 for c in tcodes) and 1 <= len(tcodes) <= 128:
@@ -87,31 +113,30 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
             if any(len(x) != m or any(c > 3 for c in x) for x in targets) or not 1 <= m <= 64:
                 continue
             u = len(up)
-            pre = _chain(targets[0][:u]) if u else ""
-            npairs = (len(targets) + 1) // 2
-            for pr in range(npairs):
-                ta = targets[2 * pr]
-                tb = targets[min(2 * pr + 1, len(targets) - 1)]      # an odd last target is paired with itself
+            pairs = _pair_up(targets, u)                     # [(barcode a, barcode b or -1, shared columns)]
+            for pr, (ba, bb, up_) in enumerate(pairs):
+                ta, tb = targets[ba], targets[bb if bb >= 0 else ba]
                 parts.append("struct QSPJ_%d_%d {\n" % (g, pr))
                 parts.append("    static __device__ __forceinline__ void pre(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
-                             % (u + 1, pre))
+                             % (up_ + 1, _chain(ta[:up_]) if up_ else ""))
                 for name, tg in (("ta", ta), ("tb", tb)):
                     parts.append("    static __device__ __forceinline__ void %s(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
-                                 % (name, m - u + 1, _chain(tg[u:])))
+                                 % (name, m - up_ + 1, _chain(tg[up_:])))
                 parts.append("};\n")
+                entries[g].append((pr, ba, bb))
             parts.append("struct QSGJ_%d {\n    static constexpr int M = %d;\n"
                          "    static __device__ __forceinline__ void run(int pair, const uint8_t* qbuf, int lane, int Lmax, h2 gL2, "
                          "u32 special, const u32 (&ltr)[4], h2 rowoff, h2 coloff, u32& ra, u32& rb) {\n        ra = 0; rb = 0;\n"
                          "        switch (pair) {\n" % (g, m))
-            for pr in range(npairs):
+            for pr, (ba, bb, up_) in enumerate(pairs):
                 parts.append("        case %d: static_barcode_rows2<M, %d, QSPJ_%d_%d>(qbuf, lane, Lmax, gL2, special, ltr, rowoff, coloff, ra, rb); break;\n"
-                             % (pr, u, g, pr))
+                             % (pr, up_, g, pr))
             parts.append("        default: break;\n        }\n    }\n};\n")
             entry.append('extern "C" __global__ void __launch_bounds__(qk::PK_WAVES * 64, 4) '
                          "qj_bc_%d(qk::StaticArgs a) { qk::barcode_static_body<qk::QSGJ_%d>(a); }\n" % (g, g))
             grp_flags[g] = 1
     parts.append("}  // namespace qk\n")
-    return "".join(parts + entry), tpl_flags, grp_flags
+    return "".join(parts + entry), tpl_flags, grp_flags, entries
 
 
 def _prelude_digest():
@@ -166,13 +191,20 @@ def attach(native_kit):
     if (not info["packed"] or (info["n_static_templates"] == info["n_templates"]
                                and info["n_static_groups"] == info["n_groups"])):
         return info
-    source, tpl_flags, grp_flags = generate(native_kit.descriptor)
+    source, tpl_flags, grp_flags, entries = generate(native_kit.descriptor)
     if not any(tpl_flags) and not any(grp_flags):
         return info
     blob = compile_source(source)
     hip = native_kit.hip
     tf = (C.c_int32 * MAX_TEMPLATES)(*tpl_flags)
     gf = (C.c_int32 * (2 * MAX_TEMPLATES))(*grp_flags)
-    hip.check(hip.lib.qcat_kit_attach_code(native_kit.handle, blob, len(blob), tf, gf))
+    offs, flat = [0], []
+    for g in range(2 * MAX_TEMPLATES):
+        for pr, ba, bb in entries[g]:
+            flat.extend((pr, ba, bb))
+        offs.append(len(flat) // 3)
+    po = (C.c_int32 * len(offs))(*offs)
+    pe = (C.c_int32 * max(1, len(flat)))(*flat)
+    hip.check(hip.lib.qcat_kit_attach_code(native_kit.handle, blob, len(blob), tf, gf, po, pe))
     native_kit._jit_blob = blob                     # keep the buffer alive as long as the kit
     return native_kit.describe()

@@ -242,3 +242,32 @@ def test_packed_detect_middle_with_custom_scoring(match, mismatch, gap):
     o_recs, o_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
     assert recs.tobytes() == o_recs.tobytes()
     assert np.array_equal(cnt, o_cnt)
+
+
+def _subset_kit(tmp_path, picks):
+    import yaml
+    lay = scanner.factory(kit="PBC096").layouts[0]
+    bcs = lay.get_barcode_set(0)
+    rows = [{"name": "barcode%02d" % (i + 1), "id": i + 1, "sequence": bcs[p].sequence, "fwd_strand": True} for i, p in enumerate(picks)]
+    data = {"kit": "SUBSET", "auto_detect": False, "description": "subset", "sequence": lay.sequence, "trim_offset": 0,
+            "barcode_set_1": rows, "barcode_set_2": []}
+    (tmp_path / "s.yml").write_text(yaml.safe_dump(data))
+    return scanner.factory(kit="SUBSET", kit_folder=str(tmp_path))
+
+
+def test_any_subset_of_a_known_barcode_family_is_static(tmp_path):
+    """the generated chains come in target pairs; a kit that uses only one target of a pair (or the
+    targets in another order) still binds: the unused half is computed and dropped"""
+    det = _subset_kit(tmp_path, [95, 2, 49, 10, 9])
+    info = native.NativeKit(det.descriptor()).describe()
+    assert info["n_static_templates"] == 1 and info["n_static_groups"] == 1
+
+
+@gpu
+def test_subset_kit_matches_the_oracle(tmp_path):
+    det = _subset_kit(tmp_path, [95, 2, 49, 10, 9])
+    reads = synth.synth_batch(800, 5, det.layouts, 0, -1, error_rate=0.08)
+    base = run(det, reads)
+    o_recs, o_cnt, o_traces, o_rows = oracle_lib.scan(base[0], reads, counts=True, trace=True, rows=True, threads=8)
+    assert base[1] == o_recs.tobytes()
+    assert np.array_equal(base[3], o_rows) and np.array_equal(base[4], o_cnt)

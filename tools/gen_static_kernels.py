@@ -51,10 +51,30 @@ def chain(letters, code):
     return " ".join(out)
 
 
+def pair_up(targets, flank):
+    """greedy pairing by longest common prefix: [(ta, tb, shared columns)]; a leftover target is paired
+    with itself.  Two targets that run in one row pass share their common prefix columns, so the
+    longer the prefix the fewer columns a pair costs (static_barcode_rows2)."""
+    rem = list(targets)
+    cand = sorted(((len(os.path.commonprefix([a, b])), a, b) for i, a in enumerate(rem) for b in rem[i + 1:]),
+                  key=lambda x: (-x[0], x[1], x[2]))
+    used, pairs = set(), []
+    for lcp, a, b in cand:
+        if a in used or b in used:
+            continue
+        used.update((a, b))
+        pairs.append((a, b, min(lcp, len(a) - 1)))
+    for t in rem:
+        if t not in used:
+            pairs.append((t, t, flank))
+    return sorted(pairs)
+
+
 def collect():
     """family (up, down) -> ordered list of distinct targets over every mode / kit selection"""
     n = qconfig.qcatConfig().barcode_context_length
     fams = collections.OrderedDict()
+    members = {}                                 # target -> the (mode, kit, template, set) groups that scan it
     templates = []
     fused = []                                   # (template A, template B): the two templates of a kit
     for mode in scanner.get_modes():
@@ -89,7 +109,8 @@ def collect():
                         lst = fams.setdefault((up, dn, len(t)), [])
                         if t not in lst:
                             lst.append(t)
-    return fams, templates, fused
+                        members.setdefault(t, set()).add((mode, kit, lay.sequence, s))
+    return fams, templates, fused, members
 
 
 class _Buf(object):
@@ -102,7 +123,7 @@ class _Buf(object):
 
 def render():
     """text of static_generated.inc plus (n kernels, n targets, n templates)"""
-    fams, templates, fused = collect()
+    fams, templates, fused, members = collect()
     reg = []
     fh = _Buf()
     if True:
@@ -112,27 +133,32 @@ def render():
         fh.write("namespace qk {\n\n")
         for kid, ((up, dn, m), targets) in enumerate(fams.items()):
             u = len(up)
-            fh.write("// kernel %d: %s + barcode + %s (%d columns, %d shared, %d targets)\n" % (kid, up, dn, m, u, len(targets)))
-            pre = chain(up, CODE) if u else ""
-            for case, t in enumerate(targets):
-                reg.append((fnv1a64([CODE[c] for c in t]), kid, case))
-            npairs = (len(targets) + 1) // 2
-            for pr in range(npairs):
-                ta = targets[2 * pr]
-                tb = targets[min(2 * pr + 1, len(targets) - 1)]      # an odd last target is paired with itself
-                fh.write("struct QSP_%d_%d {\n" % (kid, pr))
+            fh.write("// kernel %d: %s + barcode + %s (%d columns, %d-column flank, %d targets)\n" % (kid, up, dn, m, u, len(targets)))
+            # targets that are always scanned together (same set of kit groups) may be paired with each other
+            groups = collections.OrderedDict()
+            for t in targets:
+                groups.setdefault(frozenset(members[t]), []).append(t)
+            pairs = []
+            for grp in groups.values():
+                pairs.extend(pair_up(grp, u))
+            npairs = len(pairs)
+            for pr, (ta, tb, up_) in enumerate(pairs):
+                reg.append((fnv1a64([CODE[c] for c in ta]), kid, 2 * pr))
+                if tb != ta:
+                    reg.append((fnv1a64([CODE[c] for c in tb]), kid, 2 * pr + 1))
+                fh.write("struct QSP_%d_%d {      // %d shared columns\n" % (kid, pr, up_))
                 fh.write("    static __device__ __forceinline__ void pre(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
-                         % (u + 1, pre))
+                         % (up_ + 1, chain(ta[:up_], CODE) if up_ else ""))
                 for name, t in (("ta", ta), ("tb", tb)):
                     fh.write("    static __device__ __forceinline__ void %s(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
-                             % (name, m - u + 1, chain(t[u:], CODE)))
+                             % (name, m - up_ + 1, chain(t[up_:], CODE)))
                 fh.write("};\n")
             fh.write("struct QSG_%d {\n    static constexpr int M = %d;\n" % (kid, m))
             fh.write("    static __device__ __forceinline__ void run(int pair, const uint8_t* qbuf, int lane, int Lmax, h2 gL2, "
                      "u32 special, const u32 (&ltr)[4], h2 rowoff, h2 coloff, u32& ra, u32& rb) {\n        ra = 0; rb = 0;\n        switch (pair) {\n")
-            for pr in range(npairs):
+            for pr, (ta, tb, up_) in enumerate(pairs):
                 fh.write("        case %d: static_barcode_rows2<M, %d, QSP_%d_%d>(qbuf, lane, Lmax, gL2, special, ltr, rowoff, coloff, ra, rb); break;\n"
-                         % (pr, u, kid, pr))
+                         % (pr, up_, kid, pr))
             fh.write("        default: break;\n        }\n    }\n};\n\n")
         reg.sort()
         assert len(set(h for h, _, _ in reg)) == len(reg), "hash collision between targets"
