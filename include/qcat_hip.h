@@ -279,6 +279,29 @@ int  qcat_ctx_last_timing(qcat_ctx* ctx, const char** names, float* ms, int cap)
  * a few microseconds per launch). */
 int  qcat_ctx_set_timing(qcat_ctx* ctx, int enabled);
 
+/* ---- multi-GPU: reads are sharded by rank, the count vector is the only exchange ----
+ * One communicator per (context, rank); RCCL underneath (librccl is opened on the first call here).
+ * Ranks may be processes (one per GPU, the id travels by any side channel: a file, a socket, MPI)
+ * or host threads of one process (one context per device).
+ * replaces: nothing in the reference -- it is single-process; the vector that is reduced is the
+ * histogram its driver accumulates over all reads (qcat/cli.py:366-383, scanner_base.py:680-689). */
+enum { QCAT_COMM_ID_BYTES = 128, QCAT_COMM_MAX_VALUES = 64 };
+enum { QCAT_REDUCE_SUM = 0, QCAT_REDUCE_MAX = 1 };
+typedef struct qcat_comm qcat_comm;
+/* rank 0 calls this once and hands the 128 bytes to every rank. */
+int  qcat_comm_unique_id(uint8_t* id /* QCAT_COMM_ID_BYTES */);
+/* collective over the n_ranks holders of `id`; binds the communicator to ctx's device. */
+int  qcat_comm_create(qcat_ctx* ctx, int n_ranks, int rank, const uint8_t* id, qcat_comm** out);
+void qcat_comm_destroy(qcat_comm* comm);
+int  qcat_comm_info(const qcat_comm* comm, int* n_ranks, int* rank, int* device);
+/* ncclAllReduce(SUM, int64), in place on the count vector of ctx's last scan, enqueued on ctx's
+ * stream (no host synchronisation): afterwards qcat_ctx_fetch_counts returns the global counts. */
+int  qcat_counts_allreduce(qcat_ctx* ctx, qcat_comm* comm);
+/* harness helpers over the same communicator: n <= QCAT_COMM_MAX_VALUES host doubles reduced in
+ * place over all ranks (synchronises), and a barrier that also drains ctx's stream on every rank. */
+int  qcat_comm_allreduce_f64(qcat_ctx* ctx, qcat_comm* comm, double* values, int n, int op);
+int  qcat_comm_barrier(qcat_ctx* ctx, qcat_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

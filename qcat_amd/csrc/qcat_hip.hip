@@ -889,3 +889,8 @@ extern "C" int qcat_scan_batch(qcat_ctx* c, const qcat_kit* kit,
                                qcat_result* out, int64_t* counts) {
     return qcat_scan_debug(c, kit, bases, offsets, n_reads, out, counts, nullptr, nullptr, 0);
 }
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU count reduction (RCCL)
+// ------------------------------------------------------------------------------------------
+#include "comm.inc"

@@ -252,6 +252,13 @@ class HipLibrary(object):
             "qcat_ctx_results_devptr": (vp, [vp]),
             "qcat_ctx_last_timing": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
             "qcat_ctx_set_timing": (C.c_int, [vp, C.c_int]),
+            "qcat_comm_unique_id": (C.c_int, [vp]),
+            "qcat_comm_create": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+            "qcat_comm_destroy": (None, [vp]),
+            "qcat_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+            "qcat_counts_allreduce": (C.c_int, [vp, vp]),
+            "qcat_comm_allreduce_f64": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.c_int, C.c_int]),
+            "qcat_comm_barrier": (C.c_int, [vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)          # AttributeError here = ABI symbol missing
@@ -303,6 +310,59 @@ class NativeKit(object):
             except Exception:            # interpreter shutdown: the library may already be gone
                 pass
             self.handle = None
+
+
+COMM_ID_BYTES = 128
+REDUCE_SUM, REDUCE_MAX = 0, 1
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (bytes): rank 0 creates it and hands it to every rank."""
+    hip = HipLibrary.get()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    hip.check(hip.lib.qcat_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class NativeComm(object):
+    """``qcat_comm*``: one rank of the RCCL communicator that all-reduces the count vector
+    (SURVEY.md 8e).  Creation is collective over the ``n_ranks`` holders of ``unique_id``."""
+
+    def __init__(self, ctx, n_ranks, rank, unique_id):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise RuntimeError("unique id must be {} bytes".format(COMM_ID_BYTES))
+        self.hip = HipLibrary.get()
+        self.ctx = ctx
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self.hip.check(self.hip.lib.qcat_comm_create(ctx.handle, self.n_ranks, self.rank, buf, C.byref(h)))
+        self.handle = h
+
+    def allreduce_counts(self):
+        """in place on the context's device-resident count vector, stream ordered, no host sync."""
+        self.hip.check(self.hip.lib.qcat_counts_allreduce(self.ctx.handle, self.handle))
+
+    def allreduce(self, values, op=REDUCE_SUM):
+        """a few host doubles reduced over all ranks (synchronises); returns a list."""
+        arr = (C.c_double * len(values))(*[float(v) for v in values])
+        self.hip.check(self.hip.lib.qcat_comm_allreduce_f64(self.ctx.handle, self.handle, arr, len(values), op))
+        return list(arr)
+
+    def barrier(self):
+        self.hip.check(self.hip.lib.qcat_comm_barrier(self.ctx.handle, self.handle))
+
+    def close(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.hip.lib.qcat_comm_destroy(h)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class NativeContext(object):

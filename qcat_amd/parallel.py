@@ -1,11 +1,25 @@
 """Multi-GPU plumbing of the hot path: reads are independent for a fixed kit, so a
-batch is sharded by contiguous read ranges, one process per GPU, with NO data-path collective; the
-only exchange is one all-reduce (SUM, int64) of the per-barcode / per-kit count vector.
+batch is sharded by contiguous read ranges, one rank per GPU, with NO data-path collective; the
+only exchange is one all-reduce (SUM, int64) of the per-barcode / per-kit count vector, done by
+RCCL inside the native library (``qcat_counts_allreduce``, include/qcat_hip.h) in place on the
+device-resident vector.
 
-`torch.distributed` is used purely as the RCCL front end (backend "nccl" on the GPU box; "gloo" in
-the CPU tests).  Nothing here touches the kernels.
+This module is the host side of that: the shard arithmetic, the rendezvous that carries the
+128-byte RCCL unique id from rank 0 to the other ranks (a TCP socket on the node -- no PyTorch, no
+MPI), and a launcher that starts one process per GPU.  Nothing here touches the kernels.
 """
-import numpy as np
+import os
+import socket
+import struct
+import subprocess
+import sys
+import time
+
+from . import native
+
+_MAGIC_REQ = b"QCATRDZV1"
+_MAGIC_REP = b"QCATID001"
+_N_CANDIDATE_PORTS = 16
 
 
 def shard_range(n_items, rank, world_size):
@@ -17,31 +31,140 @@ def shard_range(n_items, rank, world_size):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-class _DevArray(object):
-    """Minimal __cuda_array_interface__ view of device memory owned by the native library."""
+def rank_env(environ=None):
+    """(rank, local_rank, world_size) from the launcher's environment (RANK / LOCAL_RANK /
+    WORLD_SIZE as set by ``torch.distributed.run`` or by :func:`launch`); (0, 0, 1) without one."""
+    env = os.environ if environ is None else environ
+    rank = int(env.get("RANK", "0"))
+    return rank, int(env.get("LOCAL_RANK", str(rank))), int(env.get("WORLD_SIZE", "1"))
 
-    def __init__(self, ptr, n, typestr="<i8"):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
-def allreduce_counts(counts, dist=None, device=None):
-    """Sum an int64 count vector over all ranks.  `counts`: numpy array (host) or a
-    (device_pointer, n) pair describing the library's device-resident count vector.  Returns a
-    numpy int64 array with the global counts (every rank gets the same result)."""
-    import torch
-    if dist is None:
-        import torch.distributed as dist
-    if isinstance(counts, tuple):
-        ptr, n = counts
+def _candidate_ports(environ):
+    if environ.get("QCAT_RDZV_PORT"):
+        return [int(environ["QCAT_RDZV_PORT"])]
+    base = int(environ.get("MASTER_PORT", "29500"))
+    # the launcher's own store listens on MASTER_PORT itself; the ports after it are tried in order
+    return [1024 + (base + 1 + i - 1024) % (65536 - 1024) for i in range(_N_CANDIDATE_PORTS)]
+
+
+def _recv_exact(conn, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = conn.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous connection")
+        buf += chunk
+    return buf
+
+
+def exchange_id(rank, world_size, make_id, environ=None, timeout=300.0):
+    """Rank 0 calls ``make_id()`` (-> bytes) and serves the result to the other ``world_size - 1``
+    ranks over TCP on MASTER_ADDR; every rank returns the same bytes.  The request carries the world
+    size, so a stale server of another job on a neighbouring port is told apart and skipped."""
+    env = os.environ if environ is None else environ
+    if world_size == 1:
+        return make_id()
+    addr = env.get("MASTER_ADDR", "127.0.0.1")
+    ports = _candidate_ports(env)
+    deadline = time.time() + timeout
+    if rank == 0:
+        srv = None
+        for p in ports:
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind((addr, p))
+                s.listen(world_size)
+                srv = s
+                break
+            except OSError:
+                s.close()
+        if srv is None:
+            raise RuntimeError("rendezvous: no free port among {}".format(ports))
+        payload = make_id()
+        served = set()
         try:
-            t = torch.as_tensor(_DevArray(ptr, n), device=device or "cuda").clone()
-        except Exception:            # pragma: no cover - depends on the torch build
-            raise RuntimeError("cannot view the native count vector as a torch tensor")
-    else:
-        t = torch.from_numpy(np.ascontiguousarray(counts, dtype=np.int64).copy())
-        if device is not None:
-            t = t.to(device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.cpu().numpy()
+            while len(served) < world_size - 1:
+                srv.settimeout(max(0.1, deadline - time.time()))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise RuntimeError("rendezvous: only {} of {} ranks arrived".format(len(served) + 1, world_size))
+                with conn:
+                    conn.settimeout(10.0)
+                    try:
+                        req = _recv_exact(conn, len(_MAGIC_REQ) + 8)
+                        w, r = struct.unpack("<ii", req[len(_MAGIC_REQ):])
+                        if req[:len(_MAGIC_REQ)] != _MAGIC_REQ or w != world_size or not (0 < r < world_size):
+                            continue
+                        conn.sendall(_MAGIC_REP + struct.pack("<i", len(payload)) + payload)
+                        served.add(r)
+                    except (OSError, ConnectionError, struct.error):
+                        continue
+        finally:
+            srv.close()
+        return payload
+    req = _MAGIC_REQ + struct.pack("<ii", world_size, rank)
+    while time.time() < deadline:
+        for p in ports:
+            try:
+                with socket.create_connection((addr, p), timeout=2.0) as conn:
+                    conn.settimeout(10.0)
+                    conn.sendall(req)
+                    head = _recv_exact(conn, len(_MAGIC_REP) + 4)
+                    if head[:len(_MAGIC_REP)] != _MAGIC_REP:
+                        continue
+                    (n,) = struct.unpack("<i", head[len(_MAGIC_REP):])
+                    return _recv_exact(conn, n)
+            except (OSError, ConnectionError, struct.error):
+                continue
+        time.sleep(0.05)
+    raise RuntimeError("rendezvous: rank {} could not reach rank 0 at {}:{}".format(rank, addr, ports))
+
+
+def init_comm(ctx, rank=None, world_size=None, environ=None):
+    """The RCCL communicator of this rank: rank 0 creates the unique id in the native library, the
+    id travels by :func:`exchange_id`, every rank joins (collective)."""
+    r, _lr, w = rank_env(environ)
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    uid = exchange_id(rank, world_size, native.comm_unique_id, environ)
+    return native.NativeComm(ctx, world_size, rank, uid)
+
+
+def launch(n_ranks, argv, environ=None):
+    """Start ``n_ranks`` copies of ``python argv...`` on this node, rank r bound to GPU r through
+    RANK / LOCAL_RANK / WORLD_SIZE (the variables ``torch.distributed.run`` sets), and wait for all
+    of them.  Returns the largest exit status; a failing rank takes the others down."""
+    env = dict(os.environ if environ is None else environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["QCAT_RDZV_PORT"] = str(free_port())
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n_ranks)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env)
+        e["RANK"] = e["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+    worst = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0:
+                worst = max(worst, abs(rc) or 1)
+                for q in alive:                      # one rank failed: the collective can never complete
+                    q.terminate()
+        time.sleep(0.05)
+    return worst

@@ -1,0 +1,138 @@
+"""The cross-GPU exchange of the path through the C ABI (include/qcat_hip.h: qcat_comm_*,
+qcat_counts_allreduce -- RCCL inside the library, no PyTorch): world size 1 on any box, world
+size 2 (two host threads, one context per device, and two processes started by the product's
+launcher) when the box has two GPUs.  The all-reduced histogram must equal the oracle's counts of
+the WHOLE batch (the vector of qcat/cli.py:366-383 / scanner_base.py:680-689)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import synth
+from qcat_amd import native, parallel, scanner
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scan_shard(ctx, kit, reads):
+    """resident scan of one shard; the counts stay on the device"""
+    hip = native.HipLibrary.get()
+    bases, offsets = native.pack_reads(reads)
+    batch = C.c_void_p()
+    hip.check(hip.lib.qcat_batch_upload(ctx.handle, bases.ctypes.data, offsets.ctypes.data, len(reads), C.byref(batch)))
+    hip.check(hip.lib.qcat_scan_resident(ctx.handle, kit.handle, batch))
+    return batch
+
+
+def _fetch_counts(ctx, n):
+    hip = native.HipLibrary.get()
+    out = np.zeros(n, dtype=np.int64)
+    hip.check(hip.lib.qcat_ctx_fetch_counts(ctx.handle, out.ctypes.data, n))
+    return out
+
+
+@pytest.mark.parametrize("mode,kit_name", [("epi2me", "PBC096"), ("dual", None)])
+def test_world1_counts_allreduce_is_the_identity(mode, kit_name):
+    hip = native.HipLibrary.get()
+    det = scanner.factory(mode=mode, kit=kit_name)
+    desc = det.descriptor()
+    kit = native.NativeKit(desc)
+    ctx = native.NativeContext(0)
+    reads = synth.synth_batch(500, 99, det.layouts, 1, 0, error_rate=0.08)
+    _, want = oracle_lib.scan(desc, reads, counts=True, threads=8)
+    comm = native.NativeComm(ctx, 1, 0, native.comm_unique_id())
+    n_ranks, rank, dev = C.c_int(), C.c_int(), C.c_int()
+    hip.check(hip.lib.qcat_comm_info(comm.handle, C.byref(n_ranks), C.byref(rank), C.byref(dev)))
+    assert (n_ranks.value, rank.value, dev.value) == (1, 0, 0)
+    batch = _scan_shard(ctx, kit, reads)
+    comm.allreduce_counts()
+    comm.allreduce_counts()                                   # SUM over one rank: still the same vector
+    assert np.array_equal(_fetch_counts(ctx, desc.n_count_buckets), want)
+    comm.barrier()
+    assert comm.allreduce([1.5, -2.0], native.REDUCE_SUM) == [1.5, -2.0]
+    assert comm.allreduce([3.25], native.REDUCE_MAX) == [3.25]
+    with pytest.raises(RuntimeError):
+        comm.allreduce([0.0] * 65)
+    hip.lib.qcat_batch_destroy(batch)
+    comm.close()
+
+
+def test_allreduce_needs_a_scan_and_matching_devices():
+    ctx = native.NativeContext(0)
+    comm = native.NativeComm(ctx, 1, 0, native.comm_unique_id())
+    with pytest.raises(RuntimeError, match="no scan"):
+        comm.allreduce_counts()
+    with pytest.raises(RuntimeError, match="rank"):
+        native.NativeComm(ctx, 2, 2, native.comm_unique_id())
+    comm.close()
+
+
+def _two_gpus():
+    return native.HipLibrary.get().lib.qcat_device_count() >= 2
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")
+def test_world2_threads_one_context_per_device():
+    det = scanner.factory(kit="PBC096")
+    desc = det.descriptor()
+    kit = native.NativeKit(desc)                              # one kit shared by both devices
+    n = 2001
+    reads = synth.synth_batch(n, 7, det.layouts, 1, 0, error_rate=0.08)
+    _, want = oracle_lib.scan(desc, reads, counts=True, threads=8)
+    uid = native.comm_unique_id()
+    got, errs = [None, None], []
+
+    def rank_main(r):
+        try:
+            ctx = native.NativeContext(r)
+            comm = native.NativeComm(ctx, 2, r, uid)
+            b, e = parallel.shard_range(n, r, 2)
+            batch = _scan_shard(ctx, kit, reads[b:e])
+            comm.allreduce_counts()
+            got[r] = _fetch_counts(ctx, desc.n_count_buckets)
+            assert comm.allreduce([float(r + 1)], native.REDUCE_MAX) == [2.0]
+            comm.barrier()
+            native.HipLibrary.get().lib.qcat_batch_destroy(batch)
+            comm.close()
+        except Exception as ex:                                # noqa: BLE001
+            errs.append(ex)
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errs, errs
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")
+def test_bench_starts_two_ranks_itself():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--reads", "200000"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["counts_total"] == 400000
+    assert line["count_allreduce"].startswith("rccl")
+    assert "config4" in line["config"]["workload"]
+
+
+def test_bench_under_a_launcher_environment_with_one_rank():
+    """RANK/WORLD_SIZE = 0/1 (what torch.distributed.run sets for one process): the communicator
+    path runs, RCCL included, on a one-GPU box."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(parallel.free_port()))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--reads", "100000", "--no-cpu-baseline", "--no-host-inclusive"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["counts_total"] == 100000
+    assert line["count_allreduce"].startswith("rccl") and "count_allreduce_ms" in line
+    assert "config3" in line["config"]["workload"]

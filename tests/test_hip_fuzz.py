@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import yaml
 
+import custom_kits
 import oracle_lib
 import synth
 from qcat_amd import adapters, config, native, scanner
@@ -87,17 +88,7 @@ def test_random_config_shipped_kits(seed):
     compare(det, cfg, reads, ends=rng.choice([native.ENDS_BOTH, native.ENDS_BOTH, native.ENDS_5P]))
 
 
-def _write_kit(folder, name, kit, seq, set1, set2=None, trim_offset=0):
-    def rows(bcs):
-        return [{"name": "barcode%02d" % (i + 1), "id": i + 1, "sequence": s, "fwd_strand": True} for i, s in enumerate(bcs)]
-    data = {"kit": kit, "auto_detect": False, "description": "test kit", "sequence": seq, "trim_offset": trim_offset,
-            "barcode_set_1": rows(set1), "barcode_set_2": rows(set2) if set2 else []}
-    with open(os.path.join(folder, name + ".yml"), "w") as fh:
-        yaml.safe_dump(data, fh)
-
-
-def _random_barcodes(rng, n, length=24, alphabet="ACGT"):
-    return ["".join(rng.choice(alphabet) for _ in range(length)) for _ in range(n)]
+_write_kit, _random_barcodes = custom_kits.write_kit, custom_kits.random_barcodes
 
 
 def test_custom_kit_folder_with_n_and_x(tmp_path):
@@ -124,10 +115,7 @@ def test_dual_96x96_custom_kit(tmp_path):
     """BASELINE config 5 variant: a custom dual kit whose first set also has 96 barcodes
     (9 217 barcode buckets)."""
     rng = random.Random(96)
-    folder = str(tmp_path)
-    s1, s2 = _random_barcodes(rng, 96), _random_barcodes(rng, 96)
-    _write_kit(folder, "DUAL_3p", "DUAL", "GGTTAA" + "N" * 24 + "CAGCACCTGGTGCTG" + "N" * 24 + "TTAACCTACTTGCC", s1, s2)
-    _write_kit(folder, "DUAL_5p", "DUAL", "AGGTTAA" + "N" * 24 + "CAGCACCTGGTGCTG" + "N" * 24 + "TTAACCTTTCTGTTGGTGCTGATATTGC", s1, s2)
+    folder = custom_kits.write_dual_96x96(str(tmp_path), seed=96)
     det = scanner.factory(mode="dual", kit_folder=folder)
     assert [len(l.barcode_set_1) for l in det.layouts] == [96, 96]
     d = det.descriptor()

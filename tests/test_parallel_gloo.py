@@ -1,8 +1,12 @@
-"""N > 1 path on CPU: world_size-2 gloo processes shard a batch by read range, each rank produces
-the count vector of its shard (here with the CPU oracle -- the GPU kernels are covered by the
--m gpu tests), and the all-reduced vector must equal the counts of the whole batch."""
+"""N > 1 path on CPU (no GPU here): world_size-2 processes shard a batch by read range, each rank
+produces the count vector of its shard (with the CPU oracle -- the GPU kernels and the RCCL entry
+point qcat_counts_allreduce are covered by the -m gpu tests in test_comm_gpu.py), the vectors are
+all-reduced over gloo and must equal the counts of the whole batch.  The product's own multi-rank
+plumbing -- shard arithmetic, launcher environment, the TCP rendezvous that carries the RCCL unique
+id, the rank launcher -- is exercised for real; only the collective itself is gloo instead of RCCL."""
 import os
-import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -13,6 +17,8 @@ import torch.multiprocessing as mp
 import oracle_lib
 import synth
 from qcat_amd import native, parallel, scanner
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_shard_range_partitions_exactly():
@@ -28,32 +34,38 @@ def test_shard_range_partitions_exactly():
         parallel.shard_range(10, 2, 2)
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+def test_rank_env():
+    assert parallel.rank_env({}) == (0, 0, 1)
+    assert parallel.rank_env({"RANK": "3", "WORLD_SIZE": "8"}) == (3, 3, 8)
+    assert parallel.rank_env({"RANK": "5", "LOCAL_RANK": "1", "WORLD_SIZE": "8"}) == (5, 1, 8)
 
 
 def _worker(rank, world, port, n_reads, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    # the product's rendezvous: rank 0 makes an id (RCCL's on a GPU box, random bytes here), all get it
+    uid = parallel.exchange_id(rank, world, lambda: os.urandom(native.COMM_ID_BYTES))
+    assert len(uid) == native.COMM_ID_BYTES
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = [None] * world
+    dist.all_gather_object(ids, uid)
+    assert all(i == uid for i in ids)                        # every rank holds rank 0's id
     det = scanner.factory(kit="PBC096")
     desc = det.descriptor()
     b, e = parallel.shard_range(n_reads, rank, world)
     reads = synth.synth_batch(e - b, 4711, det.layouts, 1, 0, first=b, error_rate=0.08)
     _, cnt = oracle_lib.scan(desc, reads, counts=True)
-    total = parallel.allreduce_counts(cnt, dist)
-    np.save(os.path.join(out_dir, "rank%d.npy" % rank), total)
+    t = torch.from_numpy(cnt.copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)                 # stands in for qcat_counts_allreduce (RCCL)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), t.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_count_allreduce_world2(tmp_path):
     n = 240
-    mp.spawn(_worker, args=(2, _free_port(), n, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, parallel.free_port(), n, str(tmp_path)), nprocs=2, join=True)
     det = scanner.factory(kit="PBC096")
     reads = synth.synth_batch(n, 4711, det.layouts, 1, 0, error_rate=0.08)
     _, want = oracle_lib.scan(det.descriptor(), reads, counts=True)
@@ -61,3 +73,70 @@ def test_count_allreduce_world2(tmp_path):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
         assert np.array_equal(got, want)
     assert want[:96].sum() + want[96] == n          # every read lands in exactly one barcode bucket
+
+
+_RANK_SCRIPT = """
+import os, sys
+sys.path.insert(0, {root!r})
+from qcat_amd import native, parallel
+rank, local_rank, world = parallel.rank_env()
+uid = parallel.exchange_id(rank, world, lambda: bytes(range(128)))
+open(os.path.join({out!r}, "r%d" % rank), "wb").write(uid + bytes([rank, local_rank, world]))
+sys.exit(int(os.environ.get("FAIL_RANK", "-1")) == rank)
+"""
+
+
+def test_launcher_starts_one_rank_per_gpu_and_propagates_failure(tmp_path):
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(root=ROOT, out=str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "QCAT_RDZV_PORT")}
+    assert parallel.launch(3, [str(script)], environ=env) == 0
+    for r in range(3):
+        data = (tmp_path / ("r%d" % r)).read_bytes()
+        assert data[:128] == bytes(range(128)) and list(data[128:]) == [r, r, 3]
+    env["FAIL_RANK"] = "1"
+    assert parallel.launch(2, [str(script)], environ=env) != 0
+
+
+def test_exchange_skips_a_foreign_server_on_the_first_candidate_port(tmp_path):
+    """MASTER_PORT-derived candidates: a port held by somebody else is skipped by rank 0 and told
+    apart by the other ranks (no answer / wrong magic)."""
+    import socket
+    base = parallel.free_port()
+    squat = socket.socket()
+    squat.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        squat.bind(("127.0.0.1", base + 1))
+        squat.listen(4)
+    except OSError:
+        pytest.skip("neighbouring port not available")
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(root=ROOT, out=str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("QCAT_RDZV_PORT",)}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(base), WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e))
+    try:
+        for p in procs:
+            assert p.wait(timeout=120) == 0
+    finally:
+        squat.close()
+    for r in range(2):
+        assert (tmp_path / ("r%d" % r)).read_bytes()[:128] == bytes(range(128))
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    """bench.py --gpus N must fail, not silently measure fewer devices (no GPU in this container)."""
+    if native.HipLibrary.get().lib.qcat_device_count() >= 2:
+        pytest.skip("multi-GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0
+    assert b"HIP device" in p.stderr
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="4")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr
