@@ -219,6 +219,16 @@ int  qcat_detect_kit(qcat_ctx* ctx, const qcat_kit* kit,
                      const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                      int64_t* votes, int64_t* first_read);
 
+/* replaces: BarcodeScanner.scan(read_sequence, ...) on sequences of ANY length (qcat/scanner_base.py:466-477;
+ * scanner_epi2me.py:33-144, scanner_dual.py:35-146) -- the form scan_middle uses on read interiors
+ * (scanner_base.py:479-519) and qcat/eval_full.py:199-203 on whole reads.  Every sequence is one window: all
+ * templates of `kit` are aligned to the whole sequence, the barcode region (or sequence[:max_align_length]) is
+ * scanned, and out[i] is what scan() returns -- template index, barcode index/indices, adapter_end, raw score and
+ * denominator, exit_status 0 (dual: 1 and no adapter when either barcode is missing); no thresholds, trims are 0.
+ * Windows up to max_align_length can equally go through qcat_scan_batch with QCAT_ENDS_5P (the fast kernels). */
+int  qcat_scan_sequences(qcat_ctx* ctx, const qcat_kit* kit,
+                         const uint8_t* bases, const uint64_t* offsets, uint32_t n_seqs, qcat_result* out);
+
 /* Same, plus one qcat_end_trace per scanned read end (2*n_reads entries, 5' then 3' per read;
  * n_reads entries with QCAT_ENDS_5P) and, if bc_rows != NULL, the raw score of EVERY barcode
  * alignment: bc_rows[((end * 2 + set) * row_stride) + b], row_stride >= largest set. */

@@ -511,6 +511,26 @@ int qo_scan_batch(const qcat_kit_desc* d, const uint8_t* bases, const uint64_t* 
     return qo_scan_debug(d, bases, offsets, n_reads, out, counts, NULL, NULL, 0, threads);
 }
 
+/* BarcodeScanner.scan() of whole sequences of any length (scanner_epi2me.py:33-144 / scanner_dual.py:35-146):
+ * the checker of qcat_scan_sequences.  One record per sequence, exactly what scan() returns. */
+int qo_scan_sequences(const qcat_kit_desc* d, const uint8_t* bases, const uint64_t* offsets,
+                      uint32_t n_seqs, qcat_result* out) {
+    qo_kit* k = NULL;
+    int rc = qo_kit_prepare(d, &k);
+    if (rc) return rc;
+    for (uint32_t r = 0; r < n_seqs; ++r) {
+        const uint8_t* seq = bases + offsets[r];
+        int64_t len = (int64_t)(offsets[r + 1] - offsets[r]);
+        uint8_t* w = (uint8_t*)malloc((size_t)len + 1);
+        for (int64_t i = 0; i < len; ++i) w[i] = qo_code_of[seq[i]];
+        qo_scan s = qo_scan_end(k, w, (int)len, NULL, NULL, 0);
+        qo_to_record(&s, 0, 0, &out[r]);
+        free(w);
+    }
+    qo_kit_free(k);
+    return 0;
+}
+
 /* detect_kit (scanner_base.py:662-678) over the descriptor's templates: per read, scan_ends
  * (:632-642) -> the template of the higher-scoring end (3' on ties) gets one vote.
  * votes[n_templates] receives per-TEMPLATE votes (the host folds templates onto kit names),

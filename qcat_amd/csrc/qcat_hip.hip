@@ -890,6 +890,33 @@ extern "C" int qcat_scan_batch(qcat_ctx* c, const qcat_kit* kit,
     return qcat_scan_debug(c, kit, bases, offsets, n_reads, out, counts, nullptr, nullptr, 0);
 }
 
+extern "C" int qcat_scan_sequences(qcat_ctx* c, const qcat_kit* ckit, const uint8_t* bases, const uint64_t* offsets,
+                                   uint32_t n_seqs, qcat_result* out) {
+    if (!c || !ckit || !offsets || !out) return set_err(QCAT_ERR_ARG, "qcat_scan_sequences: null argument");
+    qcat_kit* kit = const_cast<qcat_kit*>(ckit);
+    for (uint32_t r = 0; r < n_seqs; ++r)
+        if (offsets[r + 1] >= offsets[r] && offsets[r + 1] - offsets[r] >= (1ull << 31))
+            return set_err(QCAT_ERR_UNSUPPORTED, "qcat_scan_sequences: sequence longer than 2^31 - 1 bases");
+    qcat_batch* b = nullptr;
+    int rc = qcat_batch_upload(c, bases, offsets, n_seqs, &b);
+    if (rc) return rc;
+    KitOnDevice* kd = nullptr;
+    rc = kit_on_device(kit, c->device, &kd);
+    if (!rc) rc = grow(&c->results, &c->cap_reads, (size_t)n_seqs);
+    if (!rc && n_seqs) {
+        KitPtrs kp{kd->kit, kd->codes, kd->ids, kd->tables};
+        hipLaunchKernelGGL(k_scan_sequences, dim3((n_seqs + GEN_THREADS - 1) / GEN_THREADS), dim3(GEN_THREADS), 0, c->stream,
+                           kp, b->bases, b->offsets, n_seqs, c->results);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(out, c->results, (size_t)n_seqs * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = set_err(QCAT_ERR_DEVICE, std::string("qcat_scan_sequences: ") + hipGetErrorString(e));
+    }
+    c->last_n_reads = 0;                               // the context's result buffer no longer holds a batch scan
+    qcat_batch_destroy(b);
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------
 // multi-GPU count reduction (RCCL)
 // ------------------------------------------------------------------------------------------

@@ -238,6 +238,7 @@ class HipLibrary(object):
             "qcat_scan_batch": (C.c_int, [vp, vp, vp, vp, u32, vp, vp]),
             "qcat_scan_debug": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, vp, u32]),
             "qcat_detect_kit": (C.c_int, [vp, vp, vp, vp, u32, vp, vp]),
+            "qcat_scan_sequences": (C.c_int, [vp, vp, vp, vp, u32, vp]),
             "qcat_batch_upload": (C.c_int, [vp, vp, vp, u32, C.POINTER(vp)]),
             "qcat_batch_synthesize": (C.c_int, [vp, vp, C.POINTER(SynthParams), C.POINTER(vp)]),
             "qcat_batch_destroy": (None, [vp]),
@@ -393,6 +394,14 @@ class NativeContext(object):
         self.hip.check(self.hip.lib.qcat_detect_kit(self.handle, kit.handle, bases.ctypes.data,
                                                     offsets.ctypes.data, n, votes.ctypes.data, first.ctypes.data))
         return votes, first
+
+    def scan_sequences(self, kit, bases, offsets):
+        """scan() of whole sequences of any length (qcat_scan_sequences): one record per sequence."""
+        n = len(offsets) - 1
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        self.hip.check(self.hip.lib.qcat_scan_sequences(self.handle, kit.handle, bases.ctypes.data,
+                                                        offsets.ctypes.data, n, out.ctypes.data))
+        return out
 
     def scan(self, kit, bases, offsets, counts=None, trace=False, rows=False):
         n = len(offsets) - 1

@@ -137,7 +137,16 @@ def init_comm(ctx, rank=None, world_size=None, environ=None):
     rank = r if rank is None else rank
     world_size = w if world_size is None else world_size
     uid = exchange_id(rank, world_size, native.comm_unique_id, environ)
-    return native.NativeComm(ctx, world_size, rank, uid)
+    # RCCL writes a version banner to the C stdout of rank 0 while the communicator is built; callers
+    # that print machine-readable results on stdout get it on stderr instead
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        return native.NativeComm(ctx, world_size, rank, uid)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def launch(n_ranks, argv, environ=None):

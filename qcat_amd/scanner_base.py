@@ -173,9 +173,33 @@ class BarcodeScanner(object):
             barcoding_kits = [barcoding_kits]
         window = (read_sequence or "")
         if len(window) > qcat_config.max_align_length:
-            raise NotImplementedError("scan() of a window longer than max_align_length "
-                                      "(scan_middle) is not available on the MI355X path yet")
+            # a sequence longer than the end windows (scan_middle's read interiors, eval tools): every
+            # template is aligned to the WHOLE sequence, as the reference does -- qcat_scan_sequences
+            return self._scan_sequences([window], barcoding_kits, qcat_config)[0]
         return self._run([window], barcoding_kits, qcat_config, ends=native.ENDS_5P)[0]
+
+    def _scan_sequences(self, sequences, layouts, qcat_config):
+        """scan() of whole sequences of any length, one native call for the list."""
+        if not layouts:
+            raise IndexError("list index out of range")
+        kit = self._native_kit(layouts, qcat_config, native.ENDS_5P)
+        bases, offsets = native.pack_reads(sequences)
+        recs = self._context().scan_sequences(kit, bases, offsets)
+        return self._records_to_dicts(recs, layouts)
+
+    def scan_middle(self, sequence, kit_name, qcat_config):
+        """``qcat/scanner_base.py:479-519``: does the read interior ``sequence[n:-n]`` (or its reverse
+        complement) carry a barcoded adapter of kit ``kit_name`` with barcode_score >= 50?  Both strands
+        go to the device in one call; the reference's short-circuit only saves it work."""
+        from .utils import revcomp
+        detected_adapters = self.get_adapters(kit_name)
+        n = qcat_config.max_align_length
+        middle = (sequence or "")[n:-n]
+        fwd, rev = self._scan_sequences([middle, revcomp(middle)], detected_adapters, qcat_config)
+        for strand in (fwd, rev):
+            if strand and not strand["barcode_score"] < 50.0:
+                return True
+        return False
 
     def detect_barcode(self, read_sequence, read_qualities=None, qcat_config=None):
         if qcat_config is None:

@@ -10,14 +10,18 @@ The reference imports two third-party packages that are absent from this image:
 minimal stand-in modules on ``sys.path`` (written to a temp dir, never committed as part of
 the product):
   * ``parasail``: ``matrix_create`` (mutable ``pointer[0].matrix`` as qcat/config.py:247-253
-    needs), ``sg_striped_32``/``sg`` forwarding to the oracle DP ``qo_sg`` (oracle/qcat_oracle.c),
-    ``can_use_sse2``.
+    needs), ``sg_striped_32``/``sg`` computed by the INDEPENDENT scalar Python DP of
+    tests/golden/sg_independent.py (written from the published recurrence; it does not call, link
+    or share code with oracle/qcat_oracle.c), ``can_use_sse2``.
   * ``Bio.SeqIO.FastaIO.SimpleFastaParser`` / ``Bio.SeqIO.QualityIO.FastqGeneralIterator``.
 Consequence: the fixtures pin everything ABOVE the parasail call -- windowing, template
 arg-max, region slicing, the barcode arg-max quirk, thresholds, trims, conflict handling,
-dual combination, batch/kit vote -- against the reference's own code.  The DP below the call
-is the oracle's restatement in both the fixture and the test, so the fixtures do NOT pin the
-DP; that is pinned only by the reference's known answers (tests/test_oracle_reference_vectors.py).
+dual combination, batch/kit vote -- against the reference's own code, and every DP value in them
+(per-template raw score and end_query, every per-barcode raw score) is one the oracle did not
+produce: tests/test_oracle_golden.py checks the oracle's C DP against them.  What remains
+unpinned is only whether real parasail agrees with the published recurrence + rule R1 beyond the
+reference's known answers (tests/test_oracle_reference_vectors.py): parasail is not available.
+The oracle is NOT imported by this script.
 
 Template order: ``glob.glob`` is wrapped with ``sorted`` before qcat is imported, i.e. the
 sorted-by-file-name order this build fixes.
@@ -41,9 +45,10 @@ REF = "/root/reference"
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import oracle_lib  # noqa: E402
+sys.path.insert(0, HERE)
+
+import sg_independent  # noqa: E402,F401  (imported by the parasail stand-in below)
 import synth  # noqa: E402
-import numpy as np  # noqa: E402
 
 
 def install_standins():
@@ -80,11 +85,12 @@ def install_standins():
             '''))
     with open(os.path.join(d, "parasail.py"), "w") as fh:
         fh.write(textwrap.dedent('''
-            """Stand-in for parasail backed by the oracle DP (see tests/golden/make_golden.py)."""
-            import numpy as np
-            import oracle_lib
+            """Stand-in for parasail backed by the independent scalar DP tests/golden/sg_independent.py
+            (see tests/golden/make_golden.py)."""
+            import sg_independent
 
-            CALLS = {"n": 0, "cells": 0}
+            CALLS = {"n": 0, "cells": 0, "computed": 0}
+            _MEMO = {}
 
             class _Inner(object):
                 def __init__(self, flat):
@@ -101,13 +107,10 @@ def install_standins():
                     flat += [0] * (n + 1)
                     self.pointer = [_Inner(flat)]
 
-                def table7(self):
-                    """-> 7x7 int8 [target, query] over A T G C N X other."""
-                    full = "ATGCNX"
-                    idx = [self.alphabet.index(c) if c in self.alphabet else self.size - 1 for c in full]
-                    idx.append(self.size - 1)
-                    m = np.array(self.pointer[0].matrix, dtype=np.int64).reshape(self.size, self.size)
-                    return m[np.ix_(idx, idx)].astype(np.int8)
+                def scorer(self):
+                    """W(a, b) through the mapper: alphabet letters in either case, the rest -> '*'."""
+                    flat = tuple(self.pointer[0].matrix)
+                    return flat, sg_independent.make_scorer(self.alphabet, flat, self.size)
 
             class Result(object):
                 def __init__(self, score, end_query, end_ref):
@@ -122,7 +125,12 @@ def install_standins():
             def sg_striped_32(s1, s2, open, extend, matrix):
                 CALLS["n"] += 1
                 CALLS["cells"] += len(s1) * len(s2)
-                return Result(*oracle_lib.sg(s1, s2, open, extend, matrix.table7()))
+                flat, score = matrix.scorer()
+                key = (s1, s2, open, extend, matrix.alphabet, flat)
+                if key not in _MEMO:
+                    CALLS["computed"] += 1
+                    _MEMO[key] = sg_independent.sg(s1, s2, open, extend, score)
+                return Result(*_MEMO[key])
 
             sg = sg_striped_32
 
@@ -396,12 +404,45 @@ def main():
         middle.append({"mode": mode, "kit": kit, "gen": gen, "results": recs})
         print("middle %s/%s: exit codes %s" % (mode, kit, sorted(set(x["exit_status"] for x in recs))))
 
+    # 9. scan() of sequences longer than max_align_length and scan_middle() called directly
+    #    (scanner_base.py:466-519; the form qcat/eval_full.py:199-203 uses)
+    long_scan = []
+    for mode, kit in (("epi2me", "PBC096"), ("epi2me", "RBK004"), ("epi2me", None), ("dual", None)):
+        det = ref_scanner.factory(mode=mode, kit=kit)
+        lays = det.layouts
+        t5, t3 = {"PBC096": (1, 0), "RBK004": (0, -1), None: (3, 2) if mode == "epi2me" else (1, 0)}[kit]
+        gen = {"seed": seed0 + 30, "n": 12, "tpl_5p": t5, "tpl_3p": t3, "error_rate": 0.08}
+        base = synth.synth_batch(12, gen["seed"], lays, t5, t3, error_rate=gen["error_rate"])
+        seqs = []
+        for i, r in enumerate(base):
+            cut = (151, 152, 200, 299, 300, 301, 450, 640, len(r), len(r), len(r), len(r))[i]
+            s_ = r[:cut]
+            if i >= 10:
+                s_ = s_[200:] + s_[:200]          # adapter in the middle of the sequence
+            seqs.append(s_)
+        scans = []
+        for s_ in seqs:
+            tracer.take()
+            res = det.scan(s_, None, lays, [], qcat_config=cfg)
+            tracer.take()
+            scans.append(result_to_json(res, lays))
+        kit_name = lays[0].kit
+        chim = [base[i] + base[i + 6] for i in range(6)] + base[:3] + [base[0][:300], base[1][:301], ""]
+        middles = []
+        for s_ in chim:
+            tracer.take()
+            middles.append(bool(det.scan_middle(s_, kit_name, cfg)))
+            tracer.take()
+        long_scan.append({"mode": mode, "kit": kit, "gen": gen, "scan": scans, "scan_middle_kit": kit_name,
+                          "scan_middle": middles})
+        print("long scan %s/%s: %d scans, scan_middle %s" % (mode, kit, len(scans), middles))
+
     with open(os.path.join(HERE, "golden_vectors.json"), "w") as fh:
         json.dump({"generator": "tests/golden/make_golden.py",
                    "template_order": "sorted by kit file name",
-                   "dp": "oracle restatement (parasail absent) -- see make_golden.py docstring",
+                   "dp": "independent scalar Python DP tests/golden/sg_independent.py (parasail absent; the oracle is not involved) -- see make_golden.py docstring",
                    "cases": cases, "region_table": region_table, "batch": batch,
-                   "batch_fastq": per_file_votes, "middle": middle,
+                   "batch_fastq": per_file_votes, "middle": middle, "long_scan": long_scan,
                    "scan5p": {"kit": "NBD103/NBD104",
                               "gen": {"seed": seed0 + 12, "n": 48, "tpl_5p": 1, "tpl_3p": 0, "error_rate": 0.08,
                                       "no_adapter_fraction": 0.05, "insert_len": 600, "lead_min": 5, "lead_max": 40},

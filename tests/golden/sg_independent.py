@@ -1,0 +1,94 @@
+"""Independent scalar semi-global aligner, written from the published recurrence -- NOT from
+oracle/qcat_oracle.c and not calling it.  Dev tool of the fixture generators (make_golden.py,
+make_sg_vectors.py): it is what stands in for the absent third-party ``parasail`` when the
+reference's Python is executed here, so every ``tpl_raw`` / ``tpl_end`` / per-barcode row in the
+committed fixtures is a value the oracle did NOT produce.
+
+Definition (Gotoh, affine gaps, all four end gaps free; call sites
+qcat/scanner_base.py:111-117 and :214-218 -- ``parasail.sg_striped_32(s1, s2, open, extend, matrix)``):
+
+    H[i][0] = H[0][j] = 0
+    E[i][j] = max(E[i][j-1] - extend, H[i][j-1] - open)      gap in the query  (consumes target)
+    F[i][j] = max(F[i-1][j] - extend, H[i-1][j] - open)      gap in the target (consumes query)
+    H[i][j] = max(H[i-1][j-1] + W(s1[i-1], s2[j-1]), E[i][j], F[i][j])
+
+    a gap of length k costs open + (k-1)*extend.
+
+Result: the best cell of the last row (query consumed) or last column (target consumed), with
+parasail's striped end-position rule: the last row is scanned first, target index ascending, strict
+``>``; then the last column: a strictly greater cell replaces the result, an equal cell only lowers
+``end_query`` and only if ``end_ref`` already is the last target position.  Positions are 0-based
+indices of the last aligned base.
+
+The layout is deliberately different from the oracle's (which walks query rows and keeps one row):
+this one fills whole matrices column by column (target-major), so a shared indexing slip would have
+to be made twice in two different shapes to go unnoticed.
+"""
+
+NEG = -(1 << 40)
+
+
+def make_scorer(alphabet, flat, size):
+    """W(a, b) for a parasail-style matrix: ``flat`` holds size*size ints, row = mapper(b), column =
+    mapper(a); the mapper sends the alphabet's letters (either case) to their index and everything
+    else to size-1 (the '*' row/column)."""
+    index = {}
+    for k, ch in enumerate(alphabet):
+        index[ch.upper()] = k
+        index[ch.lower()] = k
+    star = size - 1
+
+    def score(a, b):
+        return flat[index.get(b, star) * size + index.get(a, star)]
+    return score
+
+
+def scorer_from_table7(table7):
+    """W(a, b) from the 7x7 [target, query] table over A T G C N X other used by the C ABI."""
+    flat = [int(v) for row in table7 for v in row]
+    return make_scorer("ATGCNX", flat, 7)
+
+
+def sg(s1, s2, gap_open, gap_extend, score):
+    """-> (score, end_query, end_ref).  s1 = query (read window / region), s2 = target."""
+    n, m = len(s1), len(s2)
+    if n == 0 or m == 0:
+        raise ValueError("empty sequence")
+    # full matrices, indexed [j][i]: column j of the target, row i of the query
+    H = [[0] * (n + 1) for _ in range(m + 1)]
+    E = [[NEG] * (n + 1) for _ in range(m + 1)]
+    F = [[NEG] * (n + 1) for _ in range(m + 1)]
+    for j in range(1, m + 1):
+        b = s2[j - 1]
+        Hp, Hc = H[j - 1], H[j]
+        Ep, Ec, Fc = E[j - 1], E[j], F[j]
+        for i in range(1, n + 1):
+            e = Ep[i] - gap_extend
+            x = Hp[i] - gap_open
+            if x > e:
+                e = x
+            f = Fc[i - 1] - gap_extend
+            x = Hc[i - 1] - gap_open
+            if x > f:
+                f = x
+            h = Hp[i - 1] + score(s1[i - 1], b)
+            if e > h:
+                h = e
+            if f > h:
+                h = f
+            Ec[i], Fc[i], Hc[i] = e, f, h
+    # last row: query fully consumed, scan the target positions in ascending order
+    best, end_query, end_ref = None, n - 1, 0
+    for j in range(1, m + 1):
+        v = H[j][n]
+        if best is None or v > best:
+            best, end_query, end_ref = v, n - 1, j - 1
+    # last column: target fully consumed
+    last = H[m]
+    for i in range(1, n + 1):
+        v = last[i]
+        if v > best:
+            best, end_query, end_ref = v, i - 1, m - 1
+        elif v == best and end_ref == m - 1 and i - 1 < end_query:
+            end_query = i - 1
+    return best, end_query, end_ref

@@ -117,3 +117,19 @@ def middle_reads(entry, layouts):
         else:
             reads.append(base[i][:120 + 17 * i])
     return reads
+
+
+def long_scan_inputs(entry, layouts):
+    """Re-create the sequences of one `long_scan` fixture (see make_golden.py section 9):
+    -> (sequences for scan(), reads for scan_middle())."""
+    g = entry["gen"]
+    base = synth.synth_batch(12, g["seed"], layouts, g["tpl_5p"], g["tpl_3p"], error_rate=g["error_rate"])
+    seqs = []
+    for i, r in enumerate(base):
+        cut = (151, 152, 200, 299, 300, 301, 450, 640, len(r), len(r), len(r), len(r))[i]
+        s = r[:cut]
+        if i >= 10:
+            s = s[200:] + s[:200]
+        seqs.append(s)
+    chim = [base[i] + base[i + 6] for i in range(6)] + base[:3] + [base[0][:300], base[1][:301], ""]
+    return seqs, chim

@@ -28,6 +28,7 @@ def lib():
         l.qo_detect_kit_votes.argtypes = [C.POINTER(native.KitDesc), vp, vp, u32, vp, vp]
         l.qo_sg.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, vp,
                             C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        l.qo_scan_sequences.argtypes = [C.POINTER(native.KitDesc), vp, vp, u32, vp]
         l.qo_count_buckets.argtypes = [C.POINTER(native.KitDesc)]
         _lib = l
     return _lib
@@ -83,3 +84,12 @@ def detect_kit_votes(descriptor, reads):
     _check(lib().qo_detect_kit_votes(descriptor.byref(), bases.ctypes.data, offsets.ctypes.data, n,
                                      votes.ctypes.data, per_read.ctypes.data))
     return votes, per_read
+
+
+def scan_sequences(descriptor, seqs):
+    """scan() of whole sequences of any length; one record per sequence."""
+    bases, offsets = native.pack_reads(seqs)
+    n = len(offsets) - 1
+    out = np.zeros(n, dtype=native.RESULT_DTYPE)
+    _check(lib().qo_scan_sequences(descriptor.byref(), bases.ctypes.data, offsets.ctypes.data, n, out.ctypes.data))
+    return out

@@ -1,5 +1,7 @@
 """Oracle vs the outputs of the reference's own Python (tests/golden/golden_vectors.json,
 made by tests/golden/make_golden.py).  Pins everything above the parasail call.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -70,4 +72,48 @@ def test_detect_middle(i):
     recs = oracle_lib.scan(det.descriptor(), reads)
     assert 997 in [int(r["exit_status"]) for r in recs]
     for rec, want in zip(recs, entry["results"]):
+        assert helpers.record_as_golden(rec, det.layouts, entry["mode"]) == want
+
+
+def test_dp_against_independent_vectors():
+    """The oracle's C DP (qo_sg) against 12 000 (score, end_query, end_ref) triples computed by the
+    independent scalar Python DP (tests/golden/sg_independent.py via make_sg_vectors.py): adapter
+    and barcode alignments as the reference runs them, adapter-free windows (end-position ties of
+    rule R1), affine gaps with open != extend, degenerate and repetitive inputs (tests/sg_cases.py)."""
+    import json
+    import os
+
+    import sg_cases
+    with open(os.path.join(helpers.GOLDEN, "sg_vectors.json")) as fh:
+        fx = json.load(fh)
+    assert fx["n"] >= 10000 and len(fx["results"]) == fx["n"]
+    st = fx["stats"]
+    assert st["ends_in_last_column"] > 1000 and st["ends_in_last_row"] > 1000 and st["ends_in_corner"] > 50
+    bad = []
+    for i, want in enumerate(fx["results"]):
+        s1, s2, go, ge, table = sg_cases.case(fx["seed"], i)
+        got = oracle_lib.sg(s1, s2, go, ge, table)
+        if list(got) != want:
+            bad.append((i, got, want))
+    assert not bad, bad[:5]
+
+
+def test_fixture_dp_values_do_not_come_from_the_oracle():
+    g = helpers.golden()
+    assert "independent" in g["dp"] and "sg_independent" in g["dp"]
+    src = open(os.path.join(helpers.GOLDEN, "make_golden.py")).read()
+    assert "import oracle_lib" not in src and "qo_sg(" not in src
+    src = open(os.path.join(helpers.GOLDEN, "sg_independent.py")).read()
+    assert "import oracle_lib" not in src and "ctypes" not in src
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_scan_of_long_sequences(i):
+    """scan() on sequences longer than max_align_length (scanner_base.py:466-477): the oracle's
+    qo_scan_sequences against the reference's own scan() outputs."""
+    entry = helpers.golden()["long_scan"][i]
+    det = scanner.factory(mode=entry["mode"], kit=entry["kit"])
+    seqs, _ = helpers.long_scan_inputs(entry, det.layouts)
+    recs = oracle_lib.scan_sequences(det.descriptor(ends=native.ENDS_5P), seqs)
+    for rec, want in zip(recs, entry["scan"]):
         assert helpers.record_as_golden(rec, det.layouts, entry["mode"]) == want

@@ -10,9 +10,6 @@ import sys
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 import oracle_lib
 import synth
@@ -40,7 +37,13 @@ def test_rank_env():
     assert parallel.rank_env({"RANK": "5", "LOCAL_RANK": "1", "WORLD_SIZE": "8"}) == (5, 1, 8)
 
 
+# torch is imported inside the tests only: it bundles its own copy of the ROCm runtime, which must not
+# be loaded into a process that runs the product's GPU tests (pytest imports every module it collects)
+
+
 def _worker(rank, world, port, n_reads, out_dir):
+    import torch
+    import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
@@ -64,6 +67,7 @@ def _worker(rank, world, port, n_reads, out_dir):
 
 
 def test_count_allreduce_world2(tmp_path):
+    import torch.multiprocessing as mp
     n = 240
     mp.spawn(_worker, args=(2, parallel.free_port(), n, str(tmp_path)), nprocs=2, join=True)
     det = scanner.factory(kit="PBC096")

@@ -1,0 +1,70 @@
+"""The boundary's scan() / scan_middle() on the GPU (qcat/scanner_base.py:466-519):
+scan() of sequences of any length and scan_middle() called directly, against the reference's own
+outputs (tests/golden/golden_vectors.json "long_scan") and record-for-record against the oracle."""
+import numpy as np
+import pytest
+
+import helpers
+import oracle_lib
+import synth
+from qcat_amd import config, native, scanner
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_scan_and_scan_middle_match_the_reference(i):
+    entry = helpers.golden()["long_scan"][i]
+    det = scanner.factory(mode=entry["mode"], kit=entry["kit"])
+    cfg = config.qcatConfig()
+    seqs, chim = helpers.long_scan_inputs(entry, det.layouts)
+    for s, want in zip(seqs, entry["scan"]):
+        res = det.scan(s, None, det.layouts, [], qcat_config=cfg)
+        got = {"barcode_id": None if res["barcode"] is None else res["barcode"].id,
+               "barcode_name": None if res["barcode"] is None else res["barcode"].name,
+               "score_hex": float(res["barcode_score"]).hex(),
+               "adapter_kit": None if res["adapter"] is None else res["adapter"].kit,
+               "adapter_idx": -1 if res["adapter"] is None else [id(l) for l in det.layouts].index(id(res["adapter"])),
+               "adapter_end": res["adapter_end"], "trim5p": res["trim5p"], "trim3p": res["trim3p"],
+               "exit_status": res["exit_status"]}
+        assert got == want
+    got = [det.scan_middle(s, entry["scan_middle_kit"], cfg) for s in chim]
+    assert got == entry["scan_middle"]
+    assert True in got and False in got
+
+
+@pytest.mark.parametrize("mode,kit,t5,t3", [("epi2me", "PBC096", 1, 0), ("epi2me", "NBD103/NBD104", 1, 0),
+                                            ("epi2me", None, 3, 2), ("dual", None, 1, 0), ("epi2me", "VMK001", 0, -1)])
+def test_scan_sequences_vs_oracle(mode, kit, t5, t3):
+    det = scanner.factory(mode=mode, kit=kit)
+    reads = synth.synth_batch(40, 31337, det.layouts, t5, t3, error_rate=0.1)
+    seqs = []
+    for i, r in enumerate(reads):
+        if i % 4 == 0:
+            seqs.append(r[: 100 + 37 * i])                   # every length class, incl. <= 150
+        elif i % 4 == 1:
+            seqs.append(r[150:-150])                         # a read interior
+        elif i % 4 == 2:
+            seqs.append((r + reads[i - 1]).lower())          # chimera, lower case
+        else:
+            seqs.append(r[:300] + "N" * 40 + "RYKM*-" + r[300:])
+    seqs += ["", "A", "N" * 500]
+    d = det.descriptor(ends=native.ENDS_5P)
+    kit_h = native.NativeKit(d)
+    bases, offsets = native.pack_reads(seqs)
+    got = native.NativeContext(0).scan_sequences(kit_h, bases, offsets)
+    want = oracle_lib.scan_sequences(d, seqs)
+    assert got.tobytes() == want.tobytes()
+    # windows up to max_align_length: the same records as the fast-kernel path (scan() of a 5' window)
+    short = [s for s in seqs if len(s) <= 150]
+    if short:
+        b2, o2 = native.pack_reads(short)
+        fast = native.NativeContext(0).scan(kit_h, b2, o2)
+        slow = native.NativeContext(0).scan_sequences(kit_h, b2, o2)
+        assert fast.tobytes() == slow.tobytes()
+
+
+def test_scan_middle_with_unknown_kit_raises_like_the_reference():
+    det = scanner.factory(kit="PBC096")
+    with pytest.raises(IndexError):
+        det.scan_middle("ACGT" * 200, "no-such-kit", config.qcatConfig())
