@@ -133,7 +133,9 @@ def main():
     det = make_scanner(a.workload, mode, kit_name, local_rank)
     cfg = qconfig.qcatConfig()
     desc = det.descriptor(qcat_config=cfg, ends=ends, scan_middle=(a.workload == "middle"))
-    kit = native.NativeKit(desc)
+    t_kit = time.perf_counter()
+    kit = native.NativeKit(desc, jit=True)      # custom kits: generated kernels compiled (hipRTC) before the first scan
+    kit_seconds = time.perf_counter() - t_kit
     ctx = native.NativeContext(local_rank)
     n_buckets = desc.n_count_buckets
     use_comm = world > 1 or "RANK" in os.environ           # launcher environment (also with one process)
@@ -235,6 +237,10 @@ def main():
                "counts_total": counts_total,
                "count_allreduce": ("rccl (qcat_counts_allreduce): in place on the device count vector, %d int64 buckets, on the scan's stream"
                                    % n_buckets) if comm is not None else "single process"}
+        info = kit.describe()
+        out["kernels"] = {"static_templates": "%d/%d" % (info["n_static_templates"], info["n_templates"]),
+                          "static_barcode_groups": "%d/%d" % (info["n_static_groups"], info["n_groups"]),
+                          "kit_prepare_s": round(kit_seconds, 2)}
         if "rccl_counts_allreduce" in avg:
             out["count_allreduce_ms"] = round(avg["rccl_counts_allreduce"], 4)
         if not a.no_host_inclusive and world == 1:

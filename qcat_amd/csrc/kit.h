@@ -11,8 +11,10 @@
 // cross-multiplication (distinct rationals with these magnitudes never round to one double).
 #pragma once
 #include <stdint.h>
+#ifndef QCAT_RTC            // (run-time compiled kit units see the device structs only: rtc_prelude.inc)
 #include <string>
 #include <vector>
+#endif
 
 #include "../../include/qcat_hip.h"
 
@@ -97,6 +99,7 @@ struct EndRec {
     int32_t bc_idx[2], bc_raw[2];
 };
 
+#ifndef QCAT_RTC
 struct HostKit {
     DevKit dk;
     std::vector<uint8_t> codes;
@@ -110,6 +113,7 @@ struct HostKit {
 };
 
 int kit_prepare(const qcat_kit_desc* d, HostKit* out, std::string* err);
+#endif
 
 inline uint8_t code_of_ascii(uint8_t c) {
     switch (c & 0xDF) {

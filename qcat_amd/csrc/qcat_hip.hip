@@ -95,9 +95,10 @@ namespace qk {
 static inline void jit_launch(int kind, int index, dim3 grid, hipStream_t stream, const void* args) {
     hipFunction_t f = nullptr;
     if (g_jit) f = kind == QCAT_JIT_ADAPTER ? g_jit->jit_ad[index] : (kind == QCAT_JIT_MIDDLE ? g_jit->jit_am[index] : g_jit->jit_bc[index]);
-    if (!f) { g_packed_err = "run-time generated kernel missing from the kit's code object"; return; }
+    if (!f) { g_packed_err = "run-time generated kernel missing from the kit's code object"; g_jit_rc = QCAT_ERR_DEVICE; return; }
     void* params[1] = {const_cast<void*>(args)};
-    (void)hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, PK_WAVES * 64, 1, 1, 0, stream, params, nullptr);
+    const hipError_t e = hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, PK_WAVES * 64, 1, 1, 0, stream, params, nullptr);
+    if (e != hipSuccess) { g_packed_err = std::string("launch of a run-time generated kernel: ") + hipGetErrorString(e); g_jit_rc = QCAT_ERR_DEVICE; }
 }
 }  // namespace qk
 
@@ -123,14 +124,41 @@ extern "C" int qcat_kit_attach_code(qcat_kit* k, const void* code, uint64_t size
     if (!k->jit_code.empty()) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: code already attached");
     HostKit& h = k->hk;
     DevKit& d = h.dk;
-    k->jit_code.assign((const uint8_t*)code, (const uint8_t*)code + size);
     const int nsets = d.mode == QCAT_MODE_DUAL ? 2 : 1;
+    // validate the pair lists BEFORE anything is bound: the barcode kernel writes its raw scores at the
+    // kit barcode indices named here, and k_barcode_select reads one score per barcode of the set
+    for (int g = 0; g < 2 * MAX_T; ++g)
+        if (pair_offsets[g] < 0 || pair_offsets[g + 1] < pair_offsets[g])
+            return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: pair_offsets must be non-negative and non-decreasing");
+    for (int t = 0; t < d.nt; ++t)
+        for (int s = 0; s < nsets; ++s) {
+            const DevSet& q = d.tpl[t].sets[s];
+            if (!group_flags[t * 2 + s] || !d.barcode_f16 || q.static_kernel >= 0 || q.n <= 0) continue;
+            const int32_t* ent = pair_entries + (size_t)pair_offsets[t * 2 + s] * 3;
+            const int np = pair_offsets[t * 2 + s + 1] - pair_offsets[t * 2 + s];
+            if (np <= 0) continue;
+            if (np > q.n) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: more target pairs than barcodes in a set");
+            std::vector<char> seen((size_t)q.n, 0);
+            int covered = 0;
+            for (int i = 0; i < np; ++i) {
+                if (ent[i * 3] < 0) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: negative pair case");
+                for (int half = 1; half <= 2; ++half) {
+                    const int32_t b = ent[i * 3 + half];
+                    if (b == -1 && half == 2) continue;                      // an unpaired target
+                    if (b < 0 || b >= q.n) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: barcode index outside its set");
+                    if (seen[(size_t)b]) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: a barcode appears in two target pairs");
+                    seen[(size_t)b] = 1; ++covered;
+                }
+            }
+            if (covered != q.n) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: the target pairs do not cover every barcode of the set");
+        }
+    k->jit_code.assign((const uint8_t*)code, (const uint8_t*)code + size);
     for (int t = 0; t < d.nt; ++t) {
         if (template_flags[t] && d.adapter_f16 && d.tpl[t].static_kernel < 0) { d.tpl[t].static_kernel = QCAT_JIT_BASE + t; k->jit_tpl[t] = true; }
         for (int s = 0; s < nsets; ++s) {
             DevSet& q = d.tpl[t].sets[s];
             if (!group_flags[t * 2 + s] || !d.barcode_f16 || q.static_kernel >= 0 || q.n <= 0) continue;
-            const int32_t* ent = pair_entries + pair_offsets[t * 2 + s] * 3;
+            const int32_t* ent = pair_entries + (size_t)pair_offsets[t * 2 + s] * 3;
             const int np = pair_offsets[t * 2 + s + 1] - pair_offsets[t * 2 + s];
             if (np <= 0) continue;
             q.static_kernel = QCAT_JIT_BASE + t * 2 + s;
@@ -404,6 +432,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
                            b->bases, b->offsets, hk.max_align, c->mid_sorted, c->mid_recs, sc->sorted, sc->jt, nsets,
                            sc->tilebuf, sc->tmeta);
     }, (int16_t*)nullptr, 0u, [](const char*) {});
+    if (!rc) rc = jit_take_error();
     if (rc) return set_err(rc, packed_last_error());
     hipLaunchKernelGGL(k_mid_finalize, dim3((n + 255) / 256), dim3(256), 0, st, kp.kit, c->mid_recs, c->mid_slot, n, c->results);
     HIPCHK(hipGetLastError());

@@ -1,23 +1,32 @@
 """Run-time generation of static-letter kernels for kits that are not in the built-in bundle.
 
 The library ships generated column chains for every template and barcode target of
-``resources/kits.json`` (``csrc/static_generated.inc``); a custom kit (``--kit-folder``) runs the
-slower table kernels.  This module emits the same chains for ONE kit descriptor, compiles them with
-``hipcc --genco`` against ``csrc/jit_prelude.inc`` and hands the code object to the library
-(``qcat_kit_attach_code``).  It is optional and off by default (a compile takes several seconds):
+``resources/kits.json`` (``csrc/static_generated.inc``); a custom kit (``--kit-folder``) would
+otherwise run the slower table kernels.  This module emits the same chains for ONE kit descriptor,
+compiles them IN PROCESS with hipRTC (``libhiprtc``, against the device-only ``csrc/rtc_prelude.inc``;
+``hipcc --genco`` against ``csrc/jit_prelude.inc`` is the fall-back when the hipRTC library is
+missing) and hands the code object to the library (``qcat_kit_attach_code``).
 
-    QCAT_AMD_JIT=1           compile for every kit that is not fully covered by the built-in kernels
-    QCAT_AMD_JIT_CACHE=dir   where code objects are kept (default ~/.cache/qcat_amd)
+    QCAT_AMD_JIT=auto        (default) custom kits start on the table kernels at once, the compile runs
+                             on a background thread (seconds to tens of seconds, cached afterwards) and
+                             the kit switches to the generated kernels when it is ready
+    QCAT_AMD_JIT=1           compile before the kit is first used (benchmarks, steady-state runs)
+    QCAT_AMD_JIT=0           never generate code
+    QCAT_AMD_JIT_CACHE=dir   where code objects are kept (default ~/.cache/qcat_amd); every cached
+                             object is stored with its SHA-256 and verified before it is loaded
 
+When no compiler is available the kit stays on the table kernels and a warning says so (once).
 There is no reference counterpart (the reference has one code path); results are identical on
 every path, which ``tests/test_jit.py`` checks against the CPU oracle.
 """
 import ctypes as C
 import hashlib
+import logging
 import os
 import shutil
 import subprocess
 import tempfile
+import threading
 
 from .codes import ASCII_TO_CODE
 
@@ -27,8 +36,62 @@ MAX_TEMPLATES = 16
 _LETTER = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4}          # code -> E[] index: A, T, G, C (+ N in templates)
 
 
+def mode():
+    """"off" | "sync" | "auto" from QCAT_AMD_JIT (default auto)."""
+    v = os.environ.get("QCAT_AMD_JIT", "auto").strip().lower()
+    if v in ("", "0", "off", "no", "false"):
+        return "off"
+    if v in ("1", "on", "yes", "true", "sync"):
+        return "sync"
+    return "auto"
+
+
 def enabled():
-    return os.environ.get("QCAT_AMD_JIT", "0") not in ("", "0")
+    return mode() != "off"
+
+
+_warned = []
+
+
+def warn_once(msg):
+    if not _warned:
+        _warned.append(msg)
+        logging.warning(msg)
+
+
+_rtc = {}
+
+
+def hiprtc():
+    """ctypes handle of libhiprtc (None when the library is not installed)."""
+    if "lib" not in _rtc:
+        lib = None
+        for name in (os.environ.get("QCAT_AMD_HIPRTC"), "libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"):
+            if not name:
+                continue
+            try:
+                lib = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if lib is not None:
+            vp = C.c_void_p
+            lib.hiprtcCreateProgram.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_int, vp, vp]
+            lib.hiprtcCompileProgram.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p)]
+            lib.hiprtcGetProgramLogSize.argtypes = [vp, C.POINTER(C.c_size_t)]
+            lib.hiprtcGetProgramLog.argtypes = [vp, C.c_char_p]
+            lib.hiprtcGetCodeSize.argtypes = [vp, C.POINTER(C.c_size_t)]
+            lib.hiprtcGetCode.argtypes = [vp, C.c_char_p]
+            lib.hiprtcDestroyProgram.argtypes = [C.POINTER(vp)]
+        _rtc["lib"] = lib
+    return _rtc["lib"]
+
+
+def compiler():
+    """"hiprtc" | "hipcc" | None: what this process would compile a kit with."""
+    if os.environ.get("QCAT_AMD_JIT_COMPILER", "") != "hipcc" and hiprtc() is not None:
+        return "hiprtc"
+    return "hipcc" if hipcc_path() is not None else None
 
 
 def hipcc_path():
@@ -149,17 +212,34 @@ def _prelude_digest():
     return h.hexdigest()
 
 
-def compile_source(source):
-    """code object bytes for ``source`` (cached by content)"""
+def _compile_hiprtc(source):
+    rtc = hiprtc()
+    prog = C.c_void_p()
+    src = source.replace('#include "jit_prelude.inc"', '#include "rtc_prelude.inc"').encode()
+    if rtc.hiprtcCreateProgram(C.byref(prog), src, b"qcat_kit.hip", 0, None, None) != 0:
+        raise RuntimeError("qcat_amd.jit: hiprtcCreateProgram failed")
+    try:
+        opts = [b"--offload-arch=" + ARCH.encode(), b"-O3", b"-std=c++17", b"-w", b"-I" + CSRC.encode()]
+        arr = (C.c_char_p * len(opts))(*opts)
+        rc = rtc.hiprtcCompileProgram(prog, len(opts), arr)
+        if rc != 0:
+            n = C.c_size_t()
+            rtc.hiprtcGetProgramLogSize(prog, C.byref(n))
+            log = C.create_string_buffer(max(1, n.value))
+            rtc.hiprtcGetProgramLog(prog, log)
+            raise RuntimeError("qcat_amd.jit: hipRTC failed (%d):\n%s" % (rc, log.value.decode(errors="replace")[-4000:]))
+        n = C.c_size_t()
+        rtc.hiprtcGetCodeSize(prog, C.byref(n))
+        blob = C.create_string_buffer(n.value)
+        if rtc.hiprtcGetCode(prog, blob) != 0 or n.value == 0:
+            raise RuntimeError("qcat_amd.jit: hiprtcGetCode failed")
+        return blob.raw
+    finally:
+        rtc.hiprtcDestroyProgram(C.byref(prog))
+
+
+def _compile_hipcc(source):
     hipcc = hipcc_path()
-    if hipcc is None:
-        raise RuntimeError("qcat_amd.jit: hipcc not found (set HIPCC); cannot generate kernels for this kit")
-    cache = os.environ.get("QCAT_AMD_JIT_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "qcat_amd")
-    key = hashlib.sha1((source + _prelude_digest() + ARCH).encode()).hexdigest()
-    path = os.path.join(cache, key + ".hsaco")
-    if os.path.exists(path):
-        with open(path, "rb") as fh:
-            return fh.read()
     tmp = tempfile.mkdtemp(prefix="qcat_jit_")
     try:
         src = os.path.join(tmp, "kit.hip")
@@ -171,25 +251,70 @@ def compile_source(source):
         if proc.returncode != 0 or not os.path.exists(out):
             raise RuntimeError("qcat_amd.jit: hipcc failed:\n" + proc.stdout.decode(errors="replace")[-4000:])
         with open(out, "rb") as fh:
-            blob = fh.read()
-        try:
-            os.makedirs(cache, exist_ok=True)
-            with open(path + ".tmp%d" % os.getpid(), "wb") as fh:
-                fh.write(blob)
-            os.replace(path + ".tmp%d" % os.getpid(), path)
-        except OSError:
-            pass                                    # read-only home: compile again next time
-        return blob
+            return fh.read()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def attach(native_kit):
+def cache_dir():
+    return os.environ.get("QCAT_AMD_JIT_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "qcat_amd")
+
+
+def _cache_load(path):
+    """the cached code object, or None when it is absent or does not match its recorded SHA-256 (a
+    truncated / tampered file must never reach hipModuleLoadData)"""
+    try:
+        with open(path, "rb") as fh:
+            blob = fh.read()
+        with open(path + ".sha256") as fh:
+            want = fh.read().strip()
+    except OSError:
+        return None
+    return blob if hashlib.sha256(blob).hexdigest() == want else None
+
+
+def _cache_store(path, blob):
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as fh:
+            fh.write(blob)
+        os.replace(tmp, path)
+        with open(tmp, "w") as fh:
+            fh.write(hashlib.sha256(blob).hexdigest() + "\n")
+        os.replace(tmp, path + ".sha256")
+    except OSError:
+        pass                                        # read-only home: compile again next time
+
+
+def compile_source(source):
+    """code object bytes for ``source`` (cached by content of the source and of the kernel headers)"""
+    how = compiler()
+    if how is None:
+        raise RuntimeError("qcat_amd.jit: neither libhiprtc nor hipcc found (QCAT_AMD_HIPRTC / HIPCC); "
+                           "cannot generate kernels for this kit")
+    key = hashlib.sha1((source + _prelude_digest() + ARCH).encode()).hexdigest()
+    path = os.path.join(cache_dir(), key + ".hsaco")
+    blob = _cache_load(path)
+    if blob is not None:
+        return blob
+    blob = _compile_hiprtc(source) if how == "hiprtc" else _compile_hipcc(source)
+    _cache_store(path, blob)
+    return blob
+
+
+def needs_code(info):
+    """does a kit with this ``describe()`` leave templates / groups on the table kernels?"""
+    return bool(info["packed"]) and not (info["n_static_templates"] == info["n_templates"]
+                                         and info["n_static_groups"] == info["n_groups"])
+
+
+def attach(native_kit, handle=None):
     """generate, compile and attach kernels for whatever the built-in registry left on the table
-    kernels; returns the kit's new ``describe()`` (unchanged when there was nothing to do)"""
+    kernels; returns the kit's new ``describe()`` (unchanged when there was nothing to do).
+    ``handle``: attach to this (not yet used) ``qcat_kit*`` instead of the kit's current one."""
     info = native_kit.describe()
-    if (not info["packed"] or (info["n_static_templates"] == info["n_templates"]
-                               and info["n_static_groups"] == info["n_groups"])):
+    if not needs_code(info):
         return info
     source, tpl_flags, grp_flags, entries = generate(native_kit.descriptor)
     if not any(tpl_flags) and not any(grp_flags):
@@ -205,6 +330,30 @@ def attach(native_kit):
         offs.append(len(flat) // 3)
     po = (C.c_int32 * len(offs))(*offs)
     pe = (C.c_int32 * max(1, len(flat)))(*flat)
-    hip.check(hip.lib.qcat_kit_attach_code(native_kit.handle, blob, len(blob), tf, gf, po, pe))
-    native_kit._jit_blob = blob                     # keep the buffer alive as long as the kit
-    return native_kit.describe()
+    hip.check(hip.lib.qcat_kit_attach_code(handle if handle is not None else native_kit.handle,
+                                           blob, len(blob), tf, gf, po, pe))
+    return native_kit.describe(handle)
+
+
+def attach_in_background(native_kit):
+    """QCAT_AMD_JIT=auto: the kit is usable at once on the table kernels; a daemon thread compiles
+    its kernels, prepares a second ``qcat_kit*`` with the code attached and publishes it through
+    ``native_kit.upgrade()`` -- scans issued after that run the generated kernels."""
+    if not needs_code(native_kit.describe()):
+        return None
+
+    def work():
+        try:
+            handle = native_kit.new_handle()
+            try:
+                attach(native_kit, handle)
+            except Exception:
+                native_kit.hip.lib.qcat_kit_destroy(handle)
+                raise
+            native_kit.upgrade(handle)
+        except Exception as exc:                     # noqa: BLE001 -- never take the scan down with it
+            warn_once("qcat_amd: run-time kernel generation failed, the kit stays on the table kernels: %s" % exc)
+
+    th = threading.Thread(target=work, name="qcat-jit", daemon=True)
+    th.start()
+    return th

@@ -7,6 +7,7 @@ there is no CPU fallback on the product path.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -282,35 +283,71 @@ class HipLibrary(object):
 
 
 class NativeKit(object):
-    """``qcat_kit*`` handle (immutable, shareable)."""
+    """``qcat_kit*`` handle (immutable, shareable).
+
+    Kits outside the built-in bundle get static-letter kernels generated at run time
+    (``qcat_amd.jit``): ``jit=True`` compiles before first use, ``jit=False`` never, ``jit=None``
+    follows QCAT_AMD_JIT (default "auto": usable at once on the table kernels, a background compile
+    swaps in a second ``qcat_kit*`` with the code attached -- ``handle`` always names the best one)."""
 
     def __init__(self, descriptor, jit=None):
-        """``jit``: compile static-letter kernels for templates / barcode sets that are not in the
-        built-in bundle (qcat_amd.jit); None = follow the QCAT_AMD_JIT environment switch."""
         self.hip = HipLibrary.get()
         self.descriptor = descriptor
-        h = C.c_void_p()
-        self.hip.check(self.hip.lib.qcat_kit_create(descriptor.byref(), C.byref(h)))
-        self.handle = h
+        self._lock = threading.Lock()
+        self._handles = [self.new_handle()]            # [-1] is current; older ones stay alive for scans in flight
+        self.jit_thread = None
         from . import jit as jit_mod
-        if jit or (jit is None and jit_mod.enabled()):
+        how = {True: "sync", False: "off", None: jit_mod.mode()}[jit]
+        if how == "off":
+            return
+        if jit_mod.compiler() is None:
+            if jit_mod.needs_code(self.describe()):
+                if jit:
+                    raise RuntimeError("qcat_amd.jit: neither libhiprtc nor hipcc found; cannot generate kernels for this kit")
+                jit_mod.warn_once("qcat_amd: no hipRTC / hipcc on this machine -- custom kits run the table kernels "
+                                  "(about 1.5x slower than generated static-letter kernels)")
+            return
+        if how == "sync":
             jit_mod.attach(self)
+        else:
+            self.jit_thread = jit_mod.attach_in_background(self)
 
-    def describe(self):
+    def new_handle(self):
+        h = C.c_void_p()
+        self.hip.check(self.hip.lib.qcat_kit_create(self.descriptor.byref(), C.byref(h)))
+        return h
+
+    @property
+    def handle(self):
+        return self._handles[-1]
+
+    def upgrade(self, handle):
+        with self._lock:
+            self._handles.append(handle)
+
+    def wait_for_code(self, timeout=None):
+        """block until a background compile (if any) has finished; returns describe()."""
+        if self.jit_thread is not None:
+            self.jit_thread.join(timeout)
+        return self.describe()
+
+    def describe(self, handle=None):
         """dict of qcat_kit_info: packed / fp16 eligibility and how many templates and barcode groups
         are bound to generated static-letter kernels."""
         info = KitInfo()
-        self.hip.check(self.hip.lib.qcat_kit_describe(self.handle, C.byref(info)))
+        self.hip.check(self.hip.lib.qcat_kit_describe(handle if handle is not None else self.handle, C.byref(info)))
         return {name: int(getattr(info, name)) for name, _ in KitInfo._fields_ if name != "reserved"}
 
     def __del__(self):
-        h = getattr(self, "handle", None)
-        if h:
+        th = getattr(self, "jit_thread", None)
+        if th is not None and th.is_alive():
+            return                                   # the compile thread still owns handles: leak rather than race
+        for h in getattr(self, "_handles", []):
             try:
                 self.hip.lib.qcat_kit_destroy(h)
             except Exception:            # interpreter shutdown: the library may already be gone
                 pass
-            self.handle = None
+        self._handles = []
 
 
 COMM_ID_BYTES = 128

@@ -21,12 +21,12 @@ pytestmark = pytest.mark.gpu
 
 
 class Resident(object):
-    def __init__(self, det, ends, n, seed, e, t5=1, t3=0):
+    def __init__(self, det, ends, n, seed, e, t5=1, t3=0, jit=None):
         self.det, self.n = det, n
         self.desc = det.descriptor(ends=ends)
         self.hip = native.HipLibrary.get()
         self.lib = self.hip.lib
-        self.kit = native.NativeKit(self.desc)
+        self.kit = native.NativeKit(self.desc, jit=jit)
         self.ctx = native.NativeContext(0)
         self.sp = native.SynthParams(seed=seed, n_reads=n, insert_len=600, lead_min=5, lead_max=40,
                                      error_rate=e, no_adapter_fraction=0.05, tpl_5p=t5, tpl_3p=t3)
@@ -66,6 +66,24 @@ def histogram_from_records(desc, layouts, recs):
     cnt[:nb + 1] = np.bincount(slots, minlength=nb + 1)
     ks = np.where(recs["adapter_idx"] >= 0, kit_slot[np.maximum(recs["adapter_idx"], 0)], nk)
     cnt[nb + 1:] = np.bincount(ks, minlength=nk + 1)
+    return cnt
+
+
+def dual_histogram_from_records(desc, layouts, recs):
+    """dual kits: barcode bucket = slot(set 1) * n_slots + slot(set 2) (include/qcat_hip.h)"""
+    nb, nk = len(desc.slot_ids), len(desc.kit_names)
+    cnt = np.zeros(desc.n_count_buckets, dtype=np.int64)
+    has = recs["barcode_idx"] >= 0
+    slots = np.full(len(recs), nb * nb, dtype=np.int64)
+    for t, lay in enumerate(layouts):
+        s1 = np.array([desc.id_slots[b.id] for b in lay.barcode_set_1])
+        s2 = np.array([desc.id_slots[b.id] for b in lay.barcode_set_2])
+        m = has & (recs["adapter_idx"] == t)
+        slots[m] = s1[recs["barcode_idx"][m]] * nb + s2[recs["barcode2_idx"][m]]
+    cnt[:nb * nb + 1] = np.bincount(slots, minlength=nb * nb + 1)
+    kit_slot = np.array([desc.kit_slots[lay.kit] for lay in layouts])
+    ks = np.where(recs["adapter_idx"] >= 0, kit_slot[np.maximum(recs["adapter_idx"], 0)], nk)
+    cnt[nb * nb + 1:] = np.bincount(ks, minlength=nk + 1)
     return cnt
 
 
@@ -134,5 +152,36 @@ def test_error_free_reads_recover_their_barcode():
             else:
                 assert recs[i]["barcode_idx"] == b and recs[i]["exit_status"] == 0
                 assert recs[i]["raw_score"] == recs[i]["score_den"]        # perfect score 100.0
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("which", ["shipped 24x96", "custom 96x96"])
+def test_config5_dual_one_million_reads(which, tmp_path):
+    """BASELINE config 5 at size on one GPU: the shipped DUAL kit (24 x 96 pairs, 14 403 buckets) and a
+    custom 96 x 96 kit (run-time generated kernels, 9 217 + ... buckets); 1 M reads each."""
+    import custom_kits
+    if which.startswith("custom"):
+        det = scanner.factory(mode="dual", kit_folder=custom_kits.write_dual_96x96(str(tmp_path)))
+        n1 = 96
+    else:
+        det = scanner.factory(mode="dual")
+        n1 = 24
+    assert [len(l.barcode_set_1) for l in det.layouts] == [n1, n1] and [len(l.barcode_set_2) for l in det.layouts] == [96, 96]
+    r = Resident(det, native.ENDS_BOTH, 1000000, 20260932, 0.08, jit=True)
+    try:
+        info = r.kit.describe()
+        assert info["packed"] == 1 and info["n_static_groups"] == info["n_groups"] == 4      # static-letter kernels either way
+        recs, cnt = r.scan()
+        nb = len(r.desc.slot_ids)
+        assert cnt[:nb * nb + 1].sum() == r.n and cnt[nb * nb + 1:].sum() == r.n            # histogram = records
+        assert np.array_equal(cnt, dual_histogram_from_records(r.desc, det.layouts, recs))
+        recs2, cnt2 = r.scan()
+        assert recs2.tobytes() == recs.tobytes() and np.array_equal(cnt, cnt2)              # idempotence
+        check_sample_against_oracle(r, recs, 1200, np.random.default_rng(5))
+        called = recs["barcode_idx"] >= 0
+        assert (recs["barcode2_idx"][called] >= 0).all() and (recs["barcode2_idx"][~called] == -1).all()
+        assert 0.5 < called.mean() < 0.96
+        assert set(np.unique(recs["exit_status"])) <= {0, 1, 1002}
     finally:
         r.close()

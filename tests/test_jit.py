@@ -15,7 +15,7 @@ import oracle_lib
 import synth
 from qcat_amd import jit, native, scanner
 
-needs_hipcc = pytest.mark.skipif(jit.hipcc_path() is None, reason="hipcc not available")
+needs_hipcc = pytest.mark.skipif(jit.compiler() is None, reason="neither libhiprtc nor hipcc available")
 
 
 def _write_kit(folder, name, kit, seq, set1, set2=None, trim_offset=0):
@@ -49,6 +49,113 @@ def test_generated_unit_compiles_and_binds_everything(tmp_path):
         info = native.NativeKit(det.descriptor(), jit=True).describe()
         assert info["n_static_templates"] == info["n_templates"] == nt
         assert info["n_static_groups"] == info["n_groups"] == ng
+
+
+@pytest.mark.skipif(jit.hiprtc() is None or jit.hipcc_path() is None, reason="needs both libhiprtc and hipcc")
+def test_hiprtc_and_hipcc_both_produce_loadable_units(tmp_path, monkeypatch):
+    """in-process hipRTC (device-only rtc_prelude.inc) is the default; hipcc --genco (jit_prelude.inc) the
+    fall-back: both must compile the same generated translation unit into a gfx950 code object"""
+    _custom_kits(str(tmp_path))
+    det = scanner.factory(mode="dual", kit_folder=os.path.join(str(tmp_path), "dual"))
+    source = jit.generate(det.descriptor())[0]
+    assert jit.compiler() == "hiprtc"
+    a = jit._compile_hiprtc(source)
+    b = jit._compile_hipcc(source)
+    for blob in (a, b):
+        assert blob[:4] in (b"\x7fELF", b"__CL") and len(blob) > 10000      # code object or clang offload bundle
+        for sym in (b"qj_ad_0", b"qj_am_0", b"qj_bc_0", b"qj_bc_1"):
+            assert sym in blob
+    monkeypatch.setenv("QCAT_AMD_JIT_COMPILER", "hipcc")
+    assert jit.compiler() == "hipcc"
+
+
+@needs_hipcc
+def test_cached_code_objects_are_verified_before_use(tmp_path, monkeypatch):
+    monkeypatch.setenv("QCAT_AMD_JIT_CACHE", str(tmp_path / "cache"))
+    _custom_kits(str(tmp_path))
+    det = scanner.factory(mode="dual", kit_folder=os.path.join(str(tmp_path), "dual"))
+    source = jit.generate(det.descriptor())[0]
+    blob = jit.compile_source(source)
+    files = sorted(os.listdir(str(tmp_path / "cache")))
+    assert len(files) == 2 and files[1] == files[0] + ".sha256"
+    path = os.path.join(str(tmp_path / "cache"), files[0])
+    calls = []
+    real = jit._compile_hiprtc if jit.compiler() == "hiprtc" else jit._compile_hipcc
+    monkeypatch.setattr(jit, "_compile_hiprtc" if jit.compiler() == "hiprtc" else "_compile_hipcc",
+                        lambda src: calls.append(1) or real(src))
+    assert jit.compile_source(source) == blob and not calls            # served from the cache
+    with open(path, "r+b") as fh:                                       # corrupt one byte of the cached object
+        fh.seek(100)
+        fh.write(b"\xff")
+    assert jit.compile_source(source) == blob and calls == [1]         # digest mismatch: compiled again, cache repaired
+    assert jit._cache_load(path) == blob
+    os.remove(path + ".sha256")                                         # an object without its digest is not trusted either
+    assert jit._cache_load(path) is None
+
+
+@needs_hipcc
+def test_auto_mode_compiles_in_the_background_and_upgrades_the_kit(tmp_path, monkeypatch):
+    monkeypatch.setenv("QCAT_AMD_JIT_CACHE", str(tmp_path / "cache"))
+    monkeypatch.setenv("QCAT_AMD_JIT", "auto")
+    _custom_kits(str(tmp_path))
+    det = scanner.factory(mode="epi2me", kit="CUSTOM", kit_folder=str(tmp_path))
+    kit = native.NativeKit(det.descriptor())
+    first = kit.handle
+    assert kit.jit_thread is not None
+    info = kit.wait_for_code(600)
+    assert info["n_static_templates"] == info["n_templates"] == 2 and info["n_static_groups"] == info["n_groups"] == 2
+    assert kit.handle is not first and kit.describe(first)["n_static_groups"] == 0   # the old handle stays valid
+    monkeypatch.setenv("QCAT_AMD_JIT", "0")
+    assert native.NativeKit(det.descriptor()).jit_thread is None
+    # shipped kits never start a compile
+    monkeypatch.setenv("QCAT_AMD_JIT", "auto")
+    assert native.NativeKit(scanner.factory(kit="PBC096").descriptor()).jit_thread is None
+
+
+def test_no_compiler_means_table_kernels_and_a_warning(tmp_path, monkeypatch, caplog):
+    monkeypatch.setattr(jit, "compiler", lambda: None)
+    monkeypatch.setattr(jit, "_warned", [])
+    _custom_kits(str(tmp_path))
+    det = scanner.factory(mode="epi2me", kit="CUSTOM", kit_folder=str(tmp_path))
+    import logging
+    with caplog.at_level(logging.WARNING):
+        kit = native.NativeKit(det.descriptor())
+    assert kit.describe()["n_static_groups"] == 0 and "table kernels" in caplog.text
+    with pytest.raises(RuntimeError, match="cannot generate kernels"):
+        native.NativeKit(det.descriptor(), jit=True)
+
+
+def test_attach_code_rejects_malformed_pair_lists(tmp_path):
+    """qcat_kit_attach_code validates what the barcode kernel will index with."""
+    import ctypes as C
+    _custom_kits(str(tmp_path))
+    det = scanner.factory(mode="epi2me", kit="CUSTOM", kit_folder=str(tmp_path))
+    hip = native.HipLibrary.get()
+    n = 20
+
+    def attach(entries, offs=None):
+        kit = native.NativeKit(det.descriptor(), jit=False)
+        tf = (C.c_int32 * 16)()
+        gf = (C.c_int32 * 32)()
+        gf[0] = 1
+        flat = [v for e in entries for v in e]
+        po = (C.c_int32 * 33)(*(offs or [0] + [len(entries)] * 32))
+        pe = (C.c_int32 * max(1, len(flat)))(*flat)
+        return hip.lib.qcat_kit_attach_code(kit.handle, b"\x7fELF" + b"\0" * 64, 68, tf, gf, po, pe), kit
+
+    good = [(i, 2 * i, 2 * i + 1) for i in range(n // 2)]
+    rc, kit = attach(good)
+    assert rc == 0 and kit.describe()["n_static_groups"] == 1
+    for bad in (good[:-1] + [(9, 18, 25)],            # barcode index outside the set
+                good[:-1] + [(9, 18, 18)],            # the same barcode twice
+                good[:-1],                            # a barcode is not covered
+                good[:-1] + [(9, -1, 19)],            # half 0 must name a barcode
+                good[:-1] + [(-1, 18, 19)]):          # negative pair case
+        rc, kit = attach(bad)
+        assert rc == -1, bad[-1]
+        assert kit.describe()["n_static_groups"] == 0            # nothing was bound
+    rc, _ = attach(good, offs=[0, 10, 5] + [5] * 30)
+    assert rc == -1
 
 
 def test_builtin_kits_need_no_code_generation(monkeypatch):

@@ -143,9 +143,9 @@ def render():
                 pairs.extend(pair_up(grp, u))
             npairs = len(pairs)
             for pr, (ta, tb, up_) in enumerate(pairs):
-                reg.append((fnv1a64([CODE[c] for c in ta]), kid, 2 * pr))
+                reg.append((fnv1a64([CODE[c] for c in ta]), kid, 2 * pr, ta))
                 if tb != ta:
-                    reg.append((fnv1a64([CODE[c] for c in tb]), kid, 2 * pr + 1))
+                    reg.append((fnv1a64([CODE[c] for c in tb]), kid, 2 * pr + 1, tb))
                 fh.write("struct QSP_%d_%d {      // %d shared columns\n" % (kid, pr, up_))
                 fh.write("    static __device__ __forceinline__ void pre(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
                          % (up_ + 1, chain(ta[:up_], CODE) if up_ else ""))
@@ -161,11 +161,12 @@ def render():
                          % (pr, up_, kid, pr))
             fh.write("        default: break;\n        }\n    }\n};\n\n")
         reg.sort()
-        assert len(set(h for h, _, _ in reg)) == len(reg), "hash collision between targets"
-        fh.write("struct StaticTarget { uint64_t hash; int16_t kernel, kase; };\n")
+        assert len(set(h for h, _, _, _ in reg)) == len(reg), "hash collision between targets"
+        fh.write("// (the hash only finds the entry; static_match compares `seq` with the kit's target before binding)\n")
+        fh.write("struct StaticTarget { uint64_t hash; int16_t kernel, kase; const char* seq; };\n")
         fh.write("static const StaticTarget g_static_targets[] = {\n")
-        for h, kid, case in reg:
-            fh.write("    {0x%016XULL, %d, %d},\n" % (h, kid, case))
+        for h, kid, case, seq in reg:
+            fh.write("    {0x%016XULL, %d, %d, \"%s\"},\n" % (h, kid, case, seq))
         fh.write("};\nstatic const int g_n_static_targets = %d;\n" % len(reg))
         fh.write("static const int g_static_kernel_M[] = {%s};\n\n" % ", ".join(str(m) for (_, _, m) in fams))
         fh.write("static inline void launch_barcode_static(int kernel, dim3 grid, hipStream_t stream, const StaticArgs& a) {\n"
@@ -181,13 +182,13 @@ def render():
             fh.write("// adapter template %d: %s\n" % (tid, seq))
             fh.write("struct QAC_%d { static __device__ __forceinline__ void run(h2 (&h)[%d], h2& carry, h2& left, "
                      "const h2 (&E)[5]) { %s } };\n" % (tid, len(seq) + 1, cols))
-            areg.append((fnv1a64([ACODE[c] for c in seq]), tid, len(seq)))
+            areg.append((fnv1a64([ACODE[c] for c in seq]), tid, len(seq), seq))
         areg.sort()
-        assert len(set(h for h, _, _ in areg)) == len(areg), "hash collision between templates"
-        fh.write("\nstruct StaticTemplate { uint64_t hash; int16_t kernel, len; };\n")
+        assert len(set(h for h, _, _, _ in areg)) == len(areg), "hash collision between templates"
+        fh.write("\nstruct StaticTemplate { uint64_t hash; int16_t kernel, len; const char* seq; };\n")
         fh.write("static const StaticTemplate g_static_templates[] = {\n")
-        for h, tid, m in areg:
-            fh.write("    {0x%016XULL, %d, %d},\n" % (h, tid, m))
+        for h, tid, m, seq in areg:
+            fh.write("    {0x%016XULL, %d, %d, \"%s\"},\n" % (h, tid, m, seq))
         fh.write("};\nstatic const int g_n_static_templates = %d;\n\n" % len(areg))
         fh.write("static inline void launch_adapter_static(int kernel, dim3 grid, hipStream_t stream, const StaticAdapterArgs& a) {\n"
                  "    if (kernel >= QCAT_JIT_BASE) { jit_launch(QCAT_JIT_ADAPTER, kernel - QCAT_JIT_BASE, grid, stream, &a); return; }\n"
@@ -207,10 +208,11 @@ def render():
                 fh.write("    static __device__ __forceinline__ void %s(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[5]) { %s }\n"
                          % (name, len(q) - u + 1, chain(q[u:], ACODE)))
             fh.write("};\n")
-        fh.write("\nstruct StaticFused { uint64_t hash_a, hash_b; int16_t kernel; };\n")
+        fh.write("\n// (tpl_a / tpl_b: the static adapter kernels of the two templates, which static_match has verified)\n")
+        fh.write("struct StaticFused { int16_t tpl_a, tpl_b, kernel; };\n")
         fh.write("static const StaticFused g_static_fused[] = {\n")
         for fid, (sa, sb) in enumerate(fused):
-            fh.write("    {0x%016XULL, 0x%016XULL, %d},\n" % (fnv1a64([ACODE[c] for c in sa]), fnv1a64([ACODE[c] for c in sb]), fid))
+            fh.write("    {%d, %d, %d},\n" % (templates.index(sa), templates.index(sb), fid))
         fh.write("};\nstatic const int g_n_static_fused = %d;\n\n" % len(fused))
         fh.write("static inline void launch_adapter_fused(int kernel, dim3 grid, hipStream_t stream, const StaticAdapterArgs& a) {\n"
                  "    switch (kernel) {\n")
