@@ -219,6 +219,19 @@ int  qcat_detect_kit(qcat_ctx* ctx, const qcat_kit* kit,
                      const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                      int64_t* votes, int64_t* first_read);
 
+/* replaces: BarcodeScanner.detect_barcode_batch with kit auto-detection (qcat/scanner_base.py:714-733): the
+ * per-batch vote of qcat_detect_kit over ALL templates of `kit`, then detect_barcode of every read with the
+ * templates of the voted kit only (override_kit_name, :527-528, :722-726).  The reference aligns the voted kit's
+ * templates a second time; here the adapter alignments of the vote stay on the device and only their merge over
+ * the voted kit's templates, the barcode phase and the finalisation follow.  out[i].adapter_idx indexes `kit`'s
+ * template list; *chosen_kit_slot = the voted kit slot (-1: empty batch); votes / first_read as in
+ * qcat_detect_kit (optional).  Returns QCAT_ERR_UNSUPPORTED for kits whose adapter pass cannot be resumed per
+ * kit (templates outside the generated static-letter kernels): call qcat_detect_kit + qcat_scan_batch then. */
+int  qcat_scan_batch_auto(qcat_ctx* ctx, const qcat_kit* kit,
+                          const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                          qcat_result* out, int64_t* counts, int32_t* chosen_kit_slot,
+                          int64_t* votes, int64_t* first_read);
+
 /* replaces: BarcodeScanner.scan(read_sequence, ...) on sequences of ANY length (qcat/scanner_base.py:466-477;
  * scanner_epi2me.py:33-144, scanner_dual.py:35-146) -- the form scan_middle uses on read interiors
  * (scanner_base.py:479-519) and qcat/eval_full.py:199-203 on whole reads.  Every sequence is one window: all

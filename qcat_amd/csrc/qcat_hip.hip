@@ -423,7 +423,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     {
         const uint32_t fblocks = (uint32_t)std::min<uint64_t>((slots + 255) / 256, 2048);
         hipLaunchKernelGGL(k_adapter_finish, dim3(fblocks), dim3(256), 0, st, kp.kit, c->mid_len, (uint32_t)slots,
-                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback);
+                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1);
     }
     const int nsets = hk.mode == QCAT_MODE_DUAL ? 2 : 1;
     rc = packed_barcode(st, kp, hk, (uint32_t)slots, c->mid_recs, sc, [&](uint32_t max_tiles) {
@@ -441,7 +441,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
 
 // core: scan a resident batch.  dbg: optional debug buffers sized by the caller.
 static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, bool debug, uint32_t row_stride,
-                              bool adapter_only = false) {
+                              bool adapter_only = false, int resume_kit_mask = -1) {
     if (!c || !kit || !b) return set_err(QCAT_ERR_ARG, "null argument");
     if (b->device != c->device) return set_err(QCAT_ERR_ARG, "batch lives on another device than the context");
     HIPCHK(hipSetDevice(c->device));
@@ -480,7 +480,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
 
     KitPtrs kp{kd->kit, kd->codes, kd->ids, kd->tables};
     g_jit = kd;
-    {
+    if (resume_kit_mask < 0) {
         uint64_t threads = (uint64_t)n_ends * (WIN_STRIDE / 16);
         uint32_t blocks = (uint32_t)((threads + 255) / 256);
         hipLaunchKernelGGL(k_pack_windows, dim3(blocks), dim3(256), 0, c->stream,
@@ -488,10 +488,12 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         mark(c, "k_pack_windows");
     }
     const bool use_packed = hk.fast_ok && !c->force_generic && packed_supported(hk);
+    if (resume_kit_mask >= 0 && !(use_packed && c->packed.slices_single))
+        return set_err(QCAT_ERR_UNSUPPORTED, "the adapter pass of this kit cannot be resumed per kit (table or general kernels)");
     if (use_packed) {
         rc = packed_scan(c->stream, kp, hk, c->win, c->wlen, (uint32_t)n_ends, c->recs, &c->packed,
                          debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride,
-                         [&](const char* nm) { mark(c, nm); }, adapter_only);
+                         [&](const char* nm) { mark(c, nm); }, adapter_only, resume_kit_mask);
         if (rc) return set_err(rc, packed_last_error());
     } else {
         uint32_t blocks = (uint32_t)((n_ends + GEN_THREADS - 1) / GEN_THREADS);
@@ -874,43 +876,88 @@ extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
     return rc;
 }
 
+// adapter-only pass over a resident batch + k_vote: per-template votes / first voting read (host arrays of MAX_T)
+static int vote_resident(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, unsigned long long* hv, unsigned long long* hf) {
+    for (int t = 0; t < MAX_T; ++t) { hv[t] = 0; hf[t] = ~0ull; }
+    int rc = scan_resident_impl(c, kit, b, false, 0, true);
+    if (rc || !b->n_reads) return rc;
+    KitOnDevice* kd = nullptr;
+    if ((rc = kit_on_device(kit, c->device, &kd))) return rc;
+    DevTemp vote_buf;
+    HIPCHK(vote_buf.alloc(2 * MAX_T * 8));
+    unsigned long long* d = vote_buf.as<unsigned long long>();
+    HIPCHK(hipMemsetAsync(d, 0, MAX_T * 8, c->stream));
+    HIPCHK(hipMemsetAsync(d + MAX_T, 0xFF, MAX_T * 8, c->stream));
+    const uint32_t blocks = std::min<uint32_t>((b->n_reads + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_vote, dim3(blocks), dim3(256), 0, c->stream, kd->kit, c->recs, b->n_reads, d, d + MAX_T);
+    HIPCHK(hipMemcpyAsync(hv, d, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hf, d + MAX_T, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 extern "C" int qcat_detect_kit(qcat_ctx* c, const qcat_kit* ckit, const uint8_t* bases, const uint64_t* offsets,
                                uint32_t n_reads, int64_t* votes, int64_t* first_read) {
     if (!c || !ckit || !offsets || !votes || !first_read) return set_err(QCAT_ERR_ARG, "null argument");
     qcat_kit* kit = const_cast<qcat_kit*>(ckit);
     if (kit->hk.dk.ends != QCAT_ENDS_BOTH) return set_err(QCAT_ERR_ARG, "qcat_detect_kit needs a kit created with QCAT_ENDS_BOTH");
     const int nt = kit->hk.dk.nt;
-    std::vector<unsigned long long> hv(MAX_T, 0), hf(MAX_T, ~0ull);
+    unsigned long long hv[MAX_T], hf[MAX_T];
     qcat_batch* b = nullptr;
     int rc = batch_upload_windows(c, kit, bases, offsets, n_reads, &b);
     if (rc) return rc;
-    rc = scan_resident_impl(c, kit, b, false, 0, true);
-    DevTemp vote_buf;
-    if (!rc && n_reads) {
-        KitOnDevice* kd = nullptr;
-        rc = kit_on_device(kit, c->device, &kd);
-        hipError_t e = hipSuccess;
-        if (!rc) e = vote_buf.alloc(2 * MAX_T * 8);
-        unsigned long long* d = vote_buf.as<unsigned long long>();
-        if (!rc && e == hipSuccess) e = hipMemsetAsync(d, 0, MAX_T * 8, c->stream);
-        if (!rc && e == hipSuccess) e = hipMemsetAsync(d + MAX_T, 0xFF, MAX_T * 8, c->stream);
-        if (!rc && e == hipSuccess) {
-            uint32_t blocks = std::min<uint32_t>((n_reads + 255) / 256, 1024);
-            hipLaunchKernelGGL(k_vote, dim3(blocks), dim3(256), 0, c->stream, kd->kit, c->recs, n_reads, d, d + MAX_T);
-            e = hipMemcpyAsync(hv.data(), d, MAX_T * 8, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(hf.data(), d + MAX_T, MAX_T * 8, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        }
-        if (!rc && e != hipSuccess) rc = set_err(QCAT_ERR_DEVICE, std::string("qcat_detect_kit: ") + hipGetErrorString(e));
-    }
+    rc = vote_resident(c, kit, b, hv, hf);
     qcat_batch_destroy(b);
     if (rc) return rc;
     for (int t = 0; t < nt; ++t) {
         votes[t] += (int64_t)hv[t];
-        int64_t f = hf[t] == ~0ull ? (int64_t)n_reads : (int64_t)hf[t];
-        first_read[t] = f;
+        first_read[t] = hf[t] == ~0ull ? (int64_t)n_reads : (int64_t)hf[t];
     }
     return 0;
+}
+
+extern "C" int qcat_scan_batch_auto(qcat_ctx* c, const qcat_kit* ckit, const uint8_t* bases, const uint64_t* offsets,
+                                    uint32_t n_reads, qcat_result* out, int64_t* counts, int32_t* chosen_kit_slot,
+                                    int64_t* votes, int64_t* first_read) {
+    if (!c || !ckit || !offsets || !out || !chosen_kit_slot) return set_err(QCAT_ERR_ARG, "qcat_scan_batch_auto: null argument");
+    qcat_kit* kit = const_cast<qcat_kit*>(ckit);
+    const DevKit& hk = kit->hk.dk;
+    if (hk.ends != QCAT_ENDS_BOTH) return set_err(QCAT_ERR_ARG, "qcat_scan_batch_auto needs a kit created with QCAT_ENDS_BOTH");
+    *chosen_kit_slot = -1;
+    qcat_batch* b = nullptr;
+    int rc = batch_upload_windows(c, kit, bases, offsets, n_reads, &b);
+    if (rc) return rc;
+    unsigned long long hv[MAX_T], hf[MAX_T];
+    rc = vote_resident(c, kit, b, hv, hf);
+    if (!rc && n_reads) {
+        // detect_kit (qcat/scanner_base.py:662-678): votes folded onto kit names; most votes wins, equal counts
+        // keep the order of first appearance (dict insertion order + stable sort, :657-660)
+        unsigned long long cnt[MAX_T] = {}, first[MAX_T];
+        for (int s = 0; s < MAX_T; ++s) first[s] = ~0ull;
+        for (int t = 0; t < hk.nt; ++t) {
+            const int s = hk.tpl[t].kit_slot;
+            cnt[s] += hv[t];
+            if (hv[t] && hf[t] < first[s]) first[s] = hf[t];
+            if (votes) votes[t] += (int64_t)hv[t];
+            if (first_read) first_read[t] = hf[t] == ~0ull ? (int64_t)n_reads : (int64_t)hf[t];
+        }
+        int best = -1;
+        for (int s = 0; s < hk.n_kit_slots; ++s)
+            if (cnt[s] && (best < 0 || cnt[s] > cnt[best] || (cnt[s] == cnt[best] && first[s] < first[best]))) best = s;
+        *chosen_kit_slot = best;
+        // detect_barcode per read with the voted kit's templates (:714-733): the adapter alignments of the vote
+        // are still on the device -- only their merge, the barcode phase and the finalisation run now
+        if (best >= 0) rc = scan_resident_impl(c, kit, b, false, 0, false, best);
+        else rc = set_err(QCAT_ERR_DEVICE, "qcat_scan_batch_auto: no read voted");
+        if (!rc) rc = qcat_ctx_fetch_results(c, out, n_reads);
+        if (!rc && counts) {
+            std::vector<int64_t> tmp((size_t)hk.n_buckets);
+            rc = qcat_ctx_fetch_counts(c, tmp.data(), hk.n_buckets);
+            if (!rc) for (size_t i = 0; i < tmp.size(); ++i) counts[i] += tmp[i];
+        }
+    }
+    qcat_batch_destroy(b);
+    return rc;
 }
 
 extern "C" int qcat_scan_batch(qcat_ctx* c, const qcat_kit* kit,

@@ -240,6 +240,7 @@ class HipLibrary(object):
             "qcat_scan_debug": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, vp, vp, u32]),
             "qcat_detect_kit": (C.c_int, [vp, vp, vp, vp, u32, vp, vp]),
             "qcat_scan_sequences": (C.c_int, [vp, vp, vp, vp, u32, vp]),
+            "qcat_scan_batch_auto": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, C.POINTER(i32), vp, vp]),
             "qcat_batch_upload": (C.c_int, [vp, vp, vp, u32, C.POINTER(vp)]),
             "qcat_batch_synthesize": (C.c_int, [vp, vp, C.POINTER(SynthParams), C.POINTER(vp)]),
             "qcat_batch_destroy": (None, [vp]),
@@ -431,6 +432,19 @@ class NativeContext(object):
         self.hip.check(self.hip.lib.qcat_detect_kit(self.handle, kit.handle, bases.ctypes.data,
                                                     offsets.ctypes.data, n, votes.ctypes.data, first.ctypes.data))
         return votes, first
+
+    def scan_auto(self, kit, bases, offsets):
+        """qcat_scan_batch_auto: (records, voted kit slot or -1); None when the kit's adapter pass cannot be
+        resumed per kit (QCAT_ERR_UNSUPPORTED) -- the caller then votes and scans in two calls."""
+        n = len(offsets) - 1
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        slot = C.c_int32(-1)
+        rc = self.hip.lib.qcat_scan_batch_auto(self.handle, kit.handle, bases.ctypes.data, offsets.ctypes.data, n,
+                                               out.ctypes.data, None, C.byref(slot), None, None)
+        if rc == -2:
+            return None
+        self.hip.check(rc)
+        return out, int(slot.value)
 
     def scan_sequences(self, kit, bases, offsets):
         """scan() of whole sequences of any length (qcat_scan_sequences): one record per sequence."""

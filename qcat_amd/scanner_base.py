@@ -253,6 +253,21 @@ class BarcodeScanner(object):
         best = sorted(counts, key=lambda kname: (-counts[kname], seen[kname]))[0]
         return best, []
 
+    def _batch_auto(self, read_sequences, n, qcat_config):
+        """Kit auto in batch mode as ONE native call (qcat_scan_batch_auto): the vote over all
+        auto-detect templates and detect_barcode with the voted kit share one adapter pass.  None when
+        it does not apply (one kit only, --detect-middle, or a kit the library cannot resume)."""
+        if (not read_sequences or not self.layouts or len(set(l.kit for l in self.layouts)) == 1
+                or self.scan_middle_adapter):
+            return None
+        kit = self._native_kit(self.layouts, qcat_config, native.ENDS_BOTH)
+        bases, offsets = native.pack_reads(read_sequences)
+        got = self._context().scan_auto(kit, bases, offsets)
+        if got is None:
+            return None
+        recs, _slot = got
+        return self._records_to_dicts(recs[:n], self.layouts)
+
     @staticmethod
     def update_barcode_count(result, barcode_count):
         key = result["barcode"].id if result and result["barcode"] else "0"
@@ -274,11 +289,13 @@ class BarcodeScanner(object):
     def detect_barcode_batch(self, read_sequences, read_qualities=[None], qcat_config=None):
         if qcat_config is None:
             qcat_config = config.qcatConfig()
-        kit_name, _ = self.detect_kit(read_sequences, qcat_config)
         # zip() in the reference truncates to the shorter list (R7)
         n = min(len(read_sequences), len(read_qualities))
-        kits = self.layouts if not kit_name else self.get_adapters(kit_name)
-        results = self._run(list(read_sequences[:n]), kits, qcat_config) if n else []
+        results = self._batch_auto(read_sequences, n, qcat_config)
+        if results is None:
+            kit_name, _ = self.detect_kit(read_sequences, qcat_config)
+            kits = self.layouts if not kit_name else self.get_adapters(kit_name)
+            results = self._run(list(read_sequences[:n]), kits, qcat_config) if n else []
         barcode_count = {}
         for res in results:
             self.update_barcode_count(res, barcode_count)

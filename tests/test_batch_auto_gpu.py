@@ -1,0 +1,151 @@
+"""Kit auto in batch mode with ONE adapter pass (qcat_scan_batch_auto; SURVEY.md 8f rank 1,
+qcat/scanner_base.py:662-678 + :714-733): the records must equal those of the reference's two-pass
+formulation -- vote over all auto-detect templates, then detect_barcode of every read with the voted
+kit's templates only -- computed here by the two separate native calls and by the oracle."""
+import time
+
+import numpy as np
+import pytest
+
+import custom_kits
+import helpers
+import oracle_lib
+import synth
+from qcat_amd import config, native, scanner
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed_batch(det, majority, n, seed):
+    """reads of three kits, `majority` most frequent, + degenerate reads"""
+    lays = det.layouts
+    by_kit = {}
+    for i, l in enumerate(lays):
+        by_kit.setdefault(l.kit, []).append(i)
+    reads = []
+    kits = [majority] + [k for k in by_kit if k != majority][:2]
+    share = [0.6, 0.25, 0.15]
+    for k, frac in zip(kits, share):
+        idx = by_kit[k]
+        t5 = idx[-1]
+        t3 = idx[0] if len(idx) > 1 else -1
+        reads += synth.synth_batch(int(n * frac), seed + len(reads), lays, t5, t3, error_rate=0.08)
+    reads += ["", "A", "N" * 200, reads[0][:140], reads[1][:301]]
+    order = np.random.default_rng(seed).permutation(len(reads))
+    return [reads[i] for i in order]
+
+
+def _two_pass(det, reads, cfg):
+    """the reference's formulation with the existing entry points: qcat_detect_kit, then qcat_scan_batch
+    on a kit made of the voted kit's templates"""
+    kit_name, _ = det.detect_kit(reads, cfg)
+    kits = det.get_adapters(kit_name)
+    return kit_name, det._run(list(reads), kits, cfg)
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x["barcode"] is y["barcode"] and x["adapter"] is y["adapter"]
+        assert float(x["barcode_score"]).hex() == float(y["barcode_score"]).hex()
+        assert (x["adapter_end"], x["trim5p"], x["trim3p"], x["exit_status"]) == (y["adapter_end"], y["trim5p"], y["trim3p"], y["exit_status"])
+
+
+@pytest.mark.parametrize("majority", ["PBC096", "RBK004", "NBD104/NBD114", "RAB204/RAB214"])
+def test_one_pass_equals_two_pass_and_oracle(majority):
+    det = scanner.factory()                                   # kit auto: the 12 auto-detect templates
+    cfg = config.qcatConfig()
+    reads = _mixed_batch(det, majority, 3000, 77)
+    kit_name, want = _two_pass(det, reads, cfg)
+    assert kit_name == majority
+    kit = det._native_kit(det.layouts, cfg, native.ENDS_BOTH)
+    bases, offsets = native.pack_reads(reads)
+    got = det._context().scan_auto(kit, bases, offsets)
+    assert got is not None, "the shipped kits must take the one-pass route"
+    recs, slot = got
+    assert kit.descriptor.kit_names[slot] == majority
+    _same(det._records_to_dicts(recs, det.layouts), want)
+    _same(det.detect_barcode_batch(reads, [None] * len(reads), cfg), want)
+    # oracle: detect_barcode with the voted kit's templates; template indices map back to the full list
+    sub = det.get_adapters(kit_name)
+    o = oracle_lib.scan(det.descriptor(layouts=sub, qcat_config=cfg), reads, threads=8)
+    full_index = np.array([det.layouts.index(l) for l in sub] + [-1])
+    o_idx = full_index[o["adapter_idx"]]
+    assert np.array_equal(o_idx, recs["adapter_idx"])
+    for name in ("barcode_idx", "barcode2_idx", "exit_status", "adapter_end", "trim5p", "trim3p", "raw_score", "score_den"):
+        assert np.array_equal(o[name], recs[name]), name
+
+
+def test_vote_ties_and_truncated_quality_list():
+    """equal vote counts -> the kit that voted first wins (dict order + stable sort, :657-660); a shorter
+    read_qualities list truncates the results but not the vote (R7)"""
+    det = scanner.factory()
+    cfg = config.qcatConfig()
+    lays = det.layouts
+    pbc = [i for i, l in enumerate(lays) if l.kit == "PBC096"]
+    rbk = [i for i, l in enumerate(lays) if l.kit == "RBK004"]
+    a = synth.synth_batch(40, 5, lays, pbc[-1], pbc[0], error_rate=0.0, no_adapter_fraction=0.0)
+    b = synth.synth_batch(40, 6, lays, rbk[0], -1, error_rate=0.0, no_adapter_fraction=0.0)
+    for first, second in ((a, b), (b, a)):
+        reads = [first[0]] + second + first[1:]
+        kit_name, want = _two_pass(det, reads, cfg)
+        assert kit_name == first_kit(det, first[0], cfg)
+        _same(det.detect_barcode_batch(reads, [None] * len(reads), cfg), want)
+        _same(det.detect_barcode_batch(reads, [None] * 7, cfg), want[:7])
+    assert det.detect_barcode_batch([], [], cfg) == []
+
+
+def first_kit(det, read, cfg):
+    return det.detect_kit([read], cfg)[0]
+
+
+def test_golden_batches_take_the_one_pass_route():
+    det = scanner.factory()
+    g = helpers.golden()
+    for fname, entry in g["batch_fastq"].items():
+        seqs = [s for _, s in helpers.fastq_records(fname)]
+        kit = det._native_kit(det.layouts, config.qcatConfig(), native.ENDS_BOTH)
+        recs, slot = det._context().scan_auto(kit, *native.pack_reads(seqs))
+        assert kit.descriptor.kit_names[slot] == entry["voted_kit"]
+        for rec, w in zip(recs, entry["results"]):
+            assert helpers.record_as_golden(rec, det.layouts, "epi2me") == w
+
+
+def test_custom_kits_on_table_kernels_fall_back_to_two_calls(tmp_path):
+    """templates outside the generated kernels share adapter slices: qcat_scan_batch_auto says
+    QCAT_ERR_UNSUPPORTED and detect_barcode_batch votes and scans in two calls -- same results."""
+    rng = __import__("random").Random(3)
+    folder = str(tmp_path)
+    for k, (name, seq) in enumerate((("KA", "GGTGCTG" + "N" * 24 + "TTAACCTTTCTGTTGGTGCTGATATTGC"),
+                                     ("KB", "CCGTGAC" + "N" * 24 + "AGAGTTTGATCATGGCTCAGGATTACC"))):
+        bcs = custom_kits.random_barcodes(rng, 8)
+        custom_kits.write_kit(folder, name, name, seq, bcs)
+    import yaml, os
+    for f in os.listdir(folder):
+        d = yaml.safe_load(open(os.path.join(folder, f)))
+        d["auto_detect"] = True
+        yaml.safe_dump(d, open(os.path.join(folder, f), "w"))
+    det = scanner.factory(kit_folder=folder)
+    assert len(det.layouts) == 2
+    cfg = config.qcatConfig()
+    reads = synth.synth_batch(300, 9, det.layouts, 0, -1, error_rate=0.05) + synth.synth_batch(100, 10, det.layouts, 1, -1, error_rate=0.05)
+    kit = native.NativeKit(det.descriptor(qcat_config=cfg), jit=False)
+    assert det._context().scan_auto(kit, *native.pack_reads(reads)) is None
+    kit_name, want = _two_pass(det, reads, cfg)
+    assert kit_name == "KA"
+
+
+def test_one_pass_is_cheaper_than_two_calls():
+    det = scanner.factory()
+    cfg = config.qcatConfig()
+    reads = _mixed_batch(det, "PBC096", 60000, 123)
+    kit = det._native_kit(det.layouts, cfg, native.ENDS_BOTH)
+    bases, offsets = native.pack_reads(reads)
+    det._context().scan_auto(kit, bases, offsets)
+    _two_pass(det, reads[:100], cfg)                          # warm both routes (kit upload, buffers)
+    t0 = time.perf_counter(); det._context().scan_auto(kit, bases, offsets); t1 = time.perf_counter()
+    votes = det._context().detect_kit(kit, bases, offsets)
+    sub = det._native_kit(det.get_adapters("PBC096"), cfg, native.ENDS_BOTH)
+    det._context().scan(sub, bases, offsets); t2 = time.perf_counter()
+    assert votes[0].sum() == len(reads)
+    assert (t1 - t0) < (t2 - t1), (t1 - t0, t2 - t1)
