@@ -27,6 +27,7 @@
 #include "kernels_static.inc"
 #include "kernels_middle.inc"
 #include "static_registry.inc"
+#include "host_pipeline.inc"
 
 using namespace qk;
 
@@ -278,6 +279,7 @@ struct qcat_ctx {
     // pinned staging of window-only uploads (qcat_scan_batch): compact bases, offsets, real lengths
     uint8_t* pin_bases = nullptr; size_t cap_pin_bases = 0;
     uint64_t* pin_offsets = nullptr; uint32_t* pin_len = nullptr; size_t cap_pin_reads = 0;
+    HostPipeline* pipe = nullptr;                  // chunked host-buffer scans (host_pipeline.inc), created on first use
     PackedScratch packed;
     // packed --detect-middle (kernels_middle.inc): M-end sort tables and per-slot arrays
     MidTables* mid_tables = nullptr;
@@ -331,6 +333,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     if (c->pin_bases) (void)hipHostFree(c->pin_bases);
     if (c->pin_offsets) (void)hipHostFree(c->pin_offsets);
     if (c->pin_len) (void)hipHostFree(c->pin_len);
+    pipeline_free(c->pipe);
     (void)hipFree(c->mid_tables); (void)hipFree(c->mid_generic); (void)hipFree(c->mid_slot); (void)hipFree(c->mid_sorted);
     (void)hipFree(c->mid_len); (void)hipFree(c->mid_fallback); (void)hipFree(c->mid_recs); (void)hipFree(c->mid_bests);
     if (c->ev_ready) for (int r = 0; r < qcat_ctx::TIME_RING; ++r) for (int i = 0; i <= MAX_TIMED; ++i) (void)hipEventDestroy(c->evr[r][i]);
@@ -441,7 +444,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
 
 // core: scan a resident batch.  dbg: optional debug buffers sized by the caller.
 static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, bool debug, uint32_t row_stride,
-                              bool adapter_only = false, int resume_kit_mask = -1) {
+                              bool adapter_only = false, int resume_kit_mask = -1, bool keep_counts = false) {
     if (!c || !kit || !b) return set_err(QCAT_ERR_ARG, "null argument");
     if (b->device != c->device) return set_err(QCAT_ERR_ARG, "batch lives on another device than the context");
     HIPCHK(hipSetDevice(c->device));
@@ -474,7 +477,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         c->ring_marks[c->ring_used] = 0;
         c->ev = c->evr[c->ring_used++];
     }
-    HIPCHK(hipMemsetAsync(c->counts, 0, (size_t)hk.n_buckets * 8, c->stream));
+    if (!keep_counts) HIPCHK(hipMemsetAsync(c->counts, 0, (size_t)hk.n_buckets * 8, c->stream));
     if (n == 0) return 0;
     if (c->timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));   // (an empty batch returned above: its slot holds no marks)
 
@@ -836,6 +839,136 @@ static void fill_trace(const HostKit& hk, const EndRec& r, const int32_t* tplraw
     }
 }
 
+// qcat_scan_batch over host buffers as a chunked pipeline (host_pipeline.inc).  Returns 1 when the batch
+// does not qualify (small, --detect-middle, disabled) and the caller should take the one-shot path.
+static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases, const uint64_t* offsets,
+                                uint32_t n_reads, qcat_result* out, int64_t* counts) {
+    const DevKit& hk = kit->hk.dk;
+    if (hk.scan_middle || n_reads < 32768 || getenv("QCAT_HIP_FULL_UPLOAD") || getenv("QCAT_HIP_NO_PIPELINE")) return 1;
+    if (!bases && offsets[n_reads] > 0) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
+    if (offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t n = (uint64_t)hk.max_align;
+    const bool both = hk.ends == QCAT_ENDS_BOTH;
+    const uint64_t keep = both ? 2 * n : n;
+    if (!c->pipe) {
+        c->pipe = new HostPipeline();
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        c->pipe->pool = new HostPool(std::min(hw, 16u) - 1);
+        HIPCHK(hipStreamCreateWithFlags(&c->pipe->copy, hipStreamNonBlocking));
+        for (PipeStage& st : c->pipe->st) {
+            HIPCHK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&st.scanned, hipEventDisableTiming));
+        }
+    }
+    HostPipeline* p = c->pipe;
+    // chunks of ~256 k reads: big enough to fill the chip (2 000+ tiles of 128 alignments), small enough that
+    // the first chunk's compaction -- the only stage nothing overlaps -- is a small part of the call
+    const char* ce = getenv("QCAT_HIP_PIPELINE_CHUNK");
+    const uint32_t chunk = ce ? (uint32_t)std::max(4096, atoi(ce)) : 262144u;
+    const uint32_t n_chunks = (n_reads + chunk - 1) / chunk;
+    if ((size_t)n_reads > p->cap_results) {
+        if (p->pin_results) (void)hipHostFree(p->pin_results);
+        p->pin_results = nullptr; p->cap_results = 0;
+        HIPCHK(hipHostMalloc((void**)&p->pin_results, (size_t)n_reads * sizeof(qcat_result)));
+        p->cap_results = n_reads;
+    }
+    for (PipeStage& st : p->st) {
+        const size_t need_reads = (size_t)chunk + 1, need_bases = (size_t)chunk * keep + 2 * BATCH_SLACK;
+        if (need_reads > st.cap_reads) {
+            if (st.pin_offsets) (void)hipHostFree(st.pin_offsets);
+            if (st.pin_len) (void)hipHostFree(st.pin_len);
+            (void)hipFree(st.dev_offsets); (void)hipFree(st.dev_len);
+            st.pin_offsets = nullptr; st.pin_len = nullptr; st.dev_offsets = nullptr; st.dev_len = nullptr; st.cap_reads = 0;
+            HIPCHK(hipHostMalloc((void**)&st.pin_offsets, need_reads * 8));
+            HIPCHK(hipHostMalloc((void**)&st.pin_len, need_reads * 4));
+            HIPCHK(hipMalloc((void**)&st.dev_offsets, need_reads * 8));
+            HIPCHK(hipMalloc((void**)&st.dev_len, need_reads * 4));
+            st.cap_reads = need_reads;
+        }
+        if (need_bases > st.cap_bases) {
+            if (st.pin_bases) (void)hipHostFree(st.pin_bases);
+            (void)hipFree(st.dev_bases_alloc);
+            st.pin_bases = nullptr; st.dev_bases_alloc = nullptr; st.cap_bases = 0;
+            HIPCHK(hipHostMalloc((void**)&st.pin_bases, need_bases));
+            HIPCHK(hipMalloc((void**)&st.dev_bases_alloc, need_bases));
+            st.cap_bases = need_bases;
+        }
+    }
+    struct TimingOff {                                   // per-kernel events describe one scan, not a chunk train
+        qcat_ctx* c; bool was;
+        explicit TimingOff(qcat_ctx* c_) : c(c_), was(c_->timing) { c->timing = false; }
+        ~TimingOff() { c->timing = was; }
+    } timing_off(c);
+    int rc = 0;
+    for (uint32_t ci = 0; ci < n_chunks && !rc; ++ci) {
+        PipeStage& st = p->st[ci & 1];
+        const uint32_t r0 = ci * chunk, nr = std::min(chunk, n_reads - r0);
+        if (ci >= 2) HIPCHK(hipEventSynchronize(st.copied));          // this slot's pinned staging has been read
+        // offsets + real lengths of the compacted chunk (serial prefix sum: ~1 ns per read)
+        uint64_t total = 0;
+        st.pin_offsets[0] = 0;
+        for (uint32_t r = 0; r < nr; ++r) {
+            const uint64_t a = offsets[r0 + r], b2 = offsets[r0 + r + 1];
+            if (b2 < a) { rc = set_err(QCAT_ERR_ARG, "offsets must be non-decreasing"); break; }
+            const uint64_t len = b2 - a;
+            if (len > 0xFFFFFFFFull) { rc = set_err(QCAT_ERR_UNSUPPORTED, "read longer than 4 Gb"); break; }
+            st.pin_len[r] = (uint32_t)len;
+            total += len <= keep ? len : keep;
+            st.pin_offsets[r + 1] = total;
+        }
+        if (rc) break;
+        const int parts = (int)std::min<uint32_t>(p->pool->size() * 4, std::max<uint32_t>(1u, nr / 4096u));
+        const uint32_t per = (nr + parts - 1) / parts;
+        p->pool->run(parts, [&](int part) {
+            const uint32_t a = std::min<uint32_t>(nr, (uint32_t)part * per), b2 = std::min<uint32_t>(nr, a + per);
+            for (uint32_t r = a; r < b2; ++r) {
+                const uint8_t* src = bases + offsets[r0 + r];
+                const uint64_t len = st.pin_len[r];
+                uint8_t* dst = st.pin_bases + st.pin_offsets[r];
+                if (len <= keep) { memcpy(dst, src, len); continue; }
+                memcpy(dst, src, n);
+                if (both) memcpy(dst + n, src + len - n, n);
+            }
+        });
+        if (ci >= 2) HIPCHK(hipStreamWaitEvent(p->copy, st.scanned, 0));   // this slot's device buffers are free again
+        if (total) HIPCHK(hipMemcpyAsync(st.dev_bases_alloc + BATCH_SLACK, st.pin_bases, total, hipMemcpyHostToDevice, p->copy));
+        HIPCHK(hipMemcpyAsync(st.dev_offsets, st.pin_offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, p->copy));
+        HIPCHK(hipMemcpyAsync(st.dev_len, st.pin_len, (size_t)nr * 4, hipMemcpyHostToDevice, p->copy));
+        HIPCHK(hipEventRecord(st.copied, p->copy));
+        HIPCHK(hipStreamWaitEvent(c->stream, st.copied, 0));
+        qcat_batch view;                                               // the chunk as a resident batch (no ownership)
+        view.device = c->device; view.n_reads = nr; view.n_bases = total;
+        view.bases_alloc = st.dev_bases_alloc; view.bases = st.dev_bases_alloc + BATCH_SLACK;
+        view.offsets = st.dev_offsets; view.true_len = st.dev_len;
+        rc = scan_resident_impl(c, kit, &view, false, 0, false, -1, /*keep_counts=*/ci > 0);
+        if (rc) break;
+        HIPCHK(hipMemcpyAsync(p->pin_results + r0, c->results, (size_t)nr * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(st.scanned, c->stream));
+    }
+    hipError_t es = hipStreamSynchronize(c->stream);
+    hipError_t ec = hipStreamSynchronize(p->copy);
+    c->last_n_reads = 0;                                 // the context's result buffer holds the last chunk only
+    if (rc) return rc;
+    if (es != hipSuccess || ec != hipSuccess)
+        return set_err(QCAT_ERR_DEVICE, std::string("qcat_scan_batch: ") + hipGetErrorString(es != hipSuccess ? es : ec));
+    {
+        const int parts = (int)std::min<uint32_t>(p->pool->size(), std::max<uint32_t>(1u, n_reads / 65536u));
+        const uint32_t per = (n_reads + parts - 1) / parts;
+        p->pool->run(parts, [&](int part) {
+            const uint32_t a = std::min<uint32_t>(n_reads, (uint32_t)part * per), b2 = std::min<uint32_t>(n_reads, a + per);
+            if (b2 > a) memcpy(out + a, p->pin_results + a, (size_t)(b2 - a) * sizeof(qcat_result));
+        });
+    }
+    if (counts) {
+        std::vector<int64_t> tmp((size_t)hk.n_buckets);
+        c->last_buckets = hk.n_buckets;
+        if ((rc = qcat_ctx_fetch_counts(c, tmp.data(), hk.n_buckets))) return rc;
+        for (size_t i = 0; i < tmp.size(); ++i) counts[i] += tmp[i];
+    }
+    return 0;
+}
+
 extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
                                const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                                qcat_result* out, int64_t* counts,
@@ -963,6 +1096,9 @@ extern "C" int qcat_scan_batch_auto(qcat_ctx* c, const qcat_kit* ckit, const uin
 extern "C" int qcat_scan_batch(qcat_ctx* c, const qcat_kit* kit,
                                const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                                qcat_result* out, int64_t* counts) {
+    if (!c || !kit || !offsets || !out) return set_err(QCAT_ERR_ARG, "null argument");
+    const int rc = scan_batch_pipelined(c, const_cast<qcat_kit*>(kit), bases, offsets, n_reads, out, counts);
+    if (rc <= 0) return rc;                           // done (0) or failed (< 0); 1 = take the one-shot path
     return qcat_scan_debug(c, kit, bases, offsets, n_reads, out, counts, nullptr, nullptr, 0);
 }
 

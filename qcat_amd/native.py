@@ -454,9 +454,14 @@ class NativeContext(object):
                                                         offsets.ctypes.data, n, out.ctypes.data))
         return out
 
-    def scan(self, kit, bases, offsets, counts=None, trace=False, rows=False):
+    def scan(self, kit, bases, offsets, counts=None, trace=False, rows=False, out=None):
+        """qcat_scan_batch / qcat_scan_debug; ``out``: a caller-owned record array to fill (reused across
+        calls it saves the page faults of a fresh 24 B x n buffer)."""
         n = len(offsets) - 1
-        out = np.zeros(n, dtype=RESULT_DTYPE)
+        if out is None:
+            out = np.empty(n, dtype=RESULT_DTYPE)
+        elif out.dtype != RESULT_DTYPE or len(out) != n or not out.flags.c_contiguous:
+            raise RuntimeError("out must be a contiguous RESULT_DTYPE array of len(offsets) - 1 records")
         cptr = counts.ctypes.data if counts is not None else None
         if not trace:
             self.hip.check(self.hip.lib.qcat_scan_batch(

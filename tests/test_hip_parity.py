@@ -279,6 +279,45 @@ def test_host_buffer_scan_uploads_windows_only():
         assert_same_as_oracle(d, reads, recs, traces, rows, cnt)
 
 
+@pytest.mark.parametrize("kit_name,mode,ends", [("NBD103/NBD104", "epi2me", native.ENDS_5P), ("PBC096", "epi2me", native.ENDS_BOTH),
+                                                (None, "dual", native.ENDS_BOTH)])
+def test_host_buffer_scan_pipeline_equals_one_shot_and_oracle(kit_name, mode, ends, monkeypatch):
+    """qcat_scan_batch on >= 32 768 reads runs as a chunked pipeline (host compaction | H2D | kernels,
+    host_pipeline.inc): records and counts must equal the one-shot path's and the oracle's, for chunk
+    sizes that do and do not divide the batch, with ragged reads at chunk borders, and repeated calls
+    on one context must reuse its staging without leaking state."""
+    det = scanner.factory(mode=mode, kit=kit_name)
+    n = 70001
+    reads = synth.synth_batch(n, 4242, det.layouts, 1, 0, error_rate=0.08)
+    for i, cut in enumerate((0, 1, 149, 150, 151, 299, 300, 301, 302, 449, 450, 451)):
+        for base in (0, 4096 - 6, 8192 - 6, 32768 - 6, n - 12):
+            reads[base + i] = reads[100 + i][:cut]
+    d = det.descriptor(ends=ends)
+    kit = native.NativeKit(d)
+    bases, offsets = native.pack_reads(reads)
+    want, want_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
+    ctx = native.NativeContext(0)
+    monkeypatch.setenv("QCAT_HIP_NO_PIPELINE", "1")
+    cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+    one_shot = ctx.scan(kit, bases, offsets, counts=cnt)
+    assert one_shot.tobytes() == want.tobytes() and np.array_equal(cnt, want_cnt)
+    monkeypatch.delenv("QCAT_HIP_NO_PIPELINE")
+    out = np.empty(n, dtype=native.RESULT_DTYPE)
+    for chunk in ("4096", "10000", "32768", None, "4096"):
+        if chunk:
+            monkeypatch.setenv("QCAT_HIP_PIPELINE_CHUNK", chunk)
+        else:
+            monkeypatch.delenv("QCAT_HIP_PIPELINE_CHUNK")
+        cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+        out[:] = 0
+        got = ctx.scan(kit, bases, offsets, counts=cnt, out=out)
+        assert got is out and got.tobytes() == want.tobytes(), chunk
+        assert np.array_equal(cnt, want_cnt), chunk
+    # a smaller batch afterwards on the same context (one-shot path) and a resident scan still work
+    small = ctx.scan(kit, *native.pack_reads(reads[:5000]))
+    assert small.tobytes() == want[:5000].tobytes()
+
+
 def test_timing_ring_and_stream_accessor():
     """qcat_ctx_last_timing averages over the scans since the previous call (no sync between scans);
     qcat_ctx_stream hands out the context's stream for stream-ordered RCCL calls."""
