@@ -188,7 +188,7 @@ def main():
     hip.check(lib.qcat_ctx_fetch_results(ctx.handle, recs.ctypes.data, a.reads))
     total_counts = np.zeros(n_buckets, dtype=np.int64)          # after the all-reduce: the global histogram
     hip.check(lib.qcat_ctx_fetch_counts(ctx.handle, total_counts.ctypes.data, n_buckets))
-    n_barcode_buckets = n_buckets - len(desc.kit_names) - 1
+    n_barcode_buckets = n_buckets - len(desc.kit_names) - 2      # [barcodes.., none][kits.., none][skipped]
     counts_total = int(total_counts[:n_barcode_buckets].sum())
     if counts_total != world * a.reads:
         sys.exit("bench.py: the count vector holds %d reads, expected %d" % (counts_total, world * a.reads))

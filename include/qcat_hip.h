@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QCAT_ABI_VERSION 2
+#define QCAT_ABI_VERSION 3
 
 /* Base code space shared by host and device (qcat_amd/codes.py): parasail's mapper sends the
  * alphabet letters (either case) to their index and everything else to the '*' row
@@ -113,6 +113,12 @@ typedef struct qcat_kit_desc {
      * kit; a barcode score >= middle_min_score (50.0) there voids the call (exit_status 997). */
     int32_t scan_middle_adapter;
     double  middle_min_score;
+    /* the driver's min-length filter for the count histogram (qcat/cli.py:521-534): a read whose sequence --
+     * after trimming to [trim5p, trim3p) when trim_reads != 0 -- is shorter than min_read_length is counted in
+     * the [skipped] bucket and in no barcode / kit bucket.  0 = no filter (update_barcode_count,
+     * scanner_base.py:680-689, counts every read). */
+    int32_t min_read_length;
+    int32_t trim_reads;
 } qcat_kit_desc;
 
 /* Result record: the dict of qcat/scanner_base.py:381-388 as indices (24 bytes, little endian).
@@ -162,8 +168,9 @@ int  qcat_device_count(void);
 /* replaces: BarcodeScanner.__init__ kit selection + qcatConfig (scanner_base.py:415-447). */
 int  qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out);
 void qcat_kit_destroy(qcat_kit* kit);
-/* number of int64 count buckets: [barcode slots.., none][kit slots.., none]
- * (dual: barcode bucket = slot1 * n_barcode_slots + slot2; cli.py:366-383, scanner_base.py:680-689) */
+/* number of int64 count buckets: [barcode slots.., none][kit slots.., none][skipped]
+ * (dual: barcode bucket = slot1 * n_barcode_slots + slot2; cli.py:366-383, scanner_base.py:680-689;
+ * [skipped] = reads under the min-length filter, cli.py:527-530 -- see qcat_kit_desc.min_read_length) */
 int  qcat_kit_count_buckets(const qcat_kit* kit);
 
 /* Which kernels a prepared kit will run (no reference counterpart: the reference has one code

@@ -459,9 +459,16 @@ static void qo_detect_barcode(const qo_kit* k, const uint8_t* read, int64_t len,
     qo_to_record(&res, trim5, trim3, o);
 }
 
-static void qo_count(const qo_kit* k, const qcat_result* r, int64_t* counts) {
+static void qo_count(const qo_kit* k, const qcat_result* r, int64_t len, int64_t* counts) {
     int nb = k->d.n_barcode_slots, nk = k->d.n_kit_slots;
     int nbuckets = (k->d.mode == QCAT_MODE_DUAL) ? nb * nb : nb;
+    if (k->d.min_read_length > 0) {                         /* the driver's filter, qcat/cli.py:521-534 */
+        if (k->d.trim_reads && k->d.ends != QCAT_ENDS_5P) { /* sequence = sequence[trim_5p:trim_3p] */
+            int64_t a = r->trim5p < len ? r->trim5p : len, b = r->trim3p < len ? r->trim3p : len;
+            len = b > a ? b - a : 0;
+        }
+        if (len < k->d.min_read_length) { counts[nbuckets + 1 + nk + 1] += 1; return; }   /* skipped_reads += 1; continue */
+    }
     int slot = nbuckets;                                    /* "none" */
     if (r->barcode_idx >= 0 && r->adapter_idx >= 0) {
         const qo_tpl* p = &k->tpl[r->adapter_idx];
@@ -476,7 +483,7 @@ static void qo_count(const qo_kit* k, const qcat_result* r, int64_t* counts) {
 
 int qo_count_buckets(const qcat_kit_desc* d) {
     int nb = d->n_barcode_slots;
-    return ((d->mode == QCAT_MODE_DUAL) ? nb * nb : nb) + 1 + d->n_kit_slots + 1;
+    return ((d->mode == QCAT_MODE_DUAL) ? nb * nb : nb) + 1 + d->n_kit_slots + 1 + 1;   /* .., [skipped] */
 }
 
 /* Batch entry point with the product's signature (minus the device context). */
@@ -501,7 +508,7 @@ int qo_scan_debug(const qcat_kit_desc* d, const uint8_t* bases, const uint64_t* 
         if (tr) memset(tr, 0, sizeof(*tr) * ends);
         qo_detect_barcode(k, read, len, &out[r], tr, rows, row_stride);
     }
-    if (counts) for (uint32_t r = 0; r < n_reads; ++r) qo_count(k, &out[r], counts);
+    if (counts) for (uint32_t r = 0; r < n_reads; ++r) qo_count(k, &out[r], (int64_t)(offsets[r + 1] - offsets[r]), counts);
     qo_kit_free(k);
     return 0;
 }

@@ -72,6 +72,7 @@ struct DevKit {
     int32_t gap_open, gap_extend, max_align, ext;
     int32_t n_barcode_slots, n_kit_slots, n_buckets;
     int32_t scan_middle;        // --detect-middle enabled
+    int32_t min_read_length, trim_reads;   // the driver's min-length filter of the histogram (qcat/cli.py:521-534)
     int32_t fast_ok;            // every template/set is eligible for the packed fast path
     int32_t barcode_f16;        // barcode tables hold binary16 high bytes (fp16-lane barcode kernels)
     uint32_t special_adapter;   // v_perm pool bytes for query codes N, X, other, PAD (adapter)

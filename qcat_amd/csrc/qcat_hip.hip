@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -523,7 +524,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
             }
             hipLaunchKernelGGL(k_scan_middle, dim3((n + GEN_THREADS - 1) / GEN_THREADS), dim3(GEN_THREADS), 0, c->stream,
                                kp, b->bases, b->offsets, n, c->results, only);
-            hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, c->stream, kp, c->results, n, c->counts);
+            hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, c->stream, kp, c->results, b->offsets, b->true_len, n, c->counts);
             mark(c, "k_scan_middle");
         }
     }
@@ -855,17 +856,24 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
         c->pipe = new HostPipeline();
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         c->pipe->pool = new HostPool(std::min(hw, 16u) - 1);
-        HIPCHK(hipStreamCreateWithFlags(&c->pipe->copy, hipStreamNonBlocking));
+        // the copy stream gets the highest priority: the runtime multiplexes streams of one priority onto a few
+        // hardware queues, and a copy queued behind a 20 ms persistent barcode kernel of a side stream would
+        // not start before that kernel ends (measured: no copy/compute overlap at all on a default stream)
+        int prio_low = 0, prio_high = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        HIPCHK(hipStreamCreateWithPriority(&c->pipe->copy, hipStreamNonBlocking, prio_high));
         for (PipeStage& st : c->pipe->st) {
             HIPCHK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&st.scanned, hipEventDisableTiming));
         }
     }
     HostPipeline* p = c->pipe;
-    // chunks of ~256 k reads: big enough to fill the chip (2 000+ tiles of 128 alignments), small enough that
-    // the first chunk's compaction -- the only stage nothing overlaps -- is a small part of the call
+    // chunks of 128 k .. 1 M reads (an eighth of the batch): big enough to fill the chip (1 000+ tiles of 128
+    // alignments), small enough that the first chunk's compaction and the last chunk's scan -- the only
+    // stages nothing overlaps -- are a small part of the call
     const char* ce = getenv("QCAT_HIP_PIPELINE_CHUNK");
-    const uint32_t chunk = ce ? (uint32_t)std::max(4096, atoi(ce)) : 262144u;
+    // (heavier per-chunk launches lose less to the tails of the persistent barcode kernels: large batches take 1 M-read chunks)
+    const uint32_t chunk = ce ? (uint32_t)std::max(4096, atoi(ce)) : std::min<uint32_t>(1048576u, std::max<uint32_t>(131072u, n_reads / 8u));
     const uint32_t n_chunks = (n_reads + chunk - 1) / chunk;
     if ((size_t)n_reads > p->cap_results) {
         if (p->pin_results) (void)hipHostFree(p->pin_results);
@@ -901,37 +909,61 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
         ~TimingOff() { c->timing = was; }
     } timing_off(c);
     int rc = 0;
+    const bool trace = getenv("QCAT_HIP_PIPELINE_TRACE") != nullptr;
+    double t_wait = 0, t_prefix = 0, t_compact = 0, t_enqueue = 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
     for (uint32_t ci = 0; ci < n_chunks && !rc; ++ci) {
         PipeStage& st = p->st[ci & 1];
+        double t0 = now();
         const uint32_t r0 = ci * chunk, nr = std::min(chunk, n_reads - r0);
         if (ci >= 2) HIPCHK(hipEventSynchronize(st.copied));          // this slot's pinned staging has been read
-        // offsets + real lengths of the compacted chunk (serial prefix sum: ~1 ns per read)
-        uint64_t total = 0;
-        st.pin_offsets[0] = 0;
-        for (uint32_t r = 0; r < nr; ++r) {
-            const uint64_t a = offsets[r0 + r], b2 = offsets[r0 + r + 1];
-            if (b2 < a) { rc = set_err(QCAT_ERR_ARG, "offsets must be non-decreasing"); break; }
-            const uint64_t len = b2 - a;
-            if (len > 0xFFFFFFFFull) { rc = set_err(QCAT_ERR_UNSUPPORTED, "read longer than 4 Gb"); break; }
-            st.pin_len[r] = (uint32_t)len;
-            total += len <= keep ? len : keep;
-            st.pin_offsets[r + 1] = total;
-        }
-        if (rc) break;
-        const int parts = (int)std::min<uint32_t>(p->pool->size() * 4, std::max<uint32_t>(1u, nr / 4096u));
+        t_wait += now() - t0; t0 = now();
+        // offsets + real lengths of the compacted chunk: per-part sums in parallel, a serial scan over the parts,
+        // then every part writes its offsets and copies its reads
+        const int parts = (int)std::min<uint32_t>(std::min<uint32_t>(p->pool->size() * 4, 256u), std::max<uint32_t>(1u, nr / 4096u));
         const uint32_t per = (nr + parts - 1) / parts;
+        uint64_t part_total[256];
+        int part_err[256];
         p->pool->run(parts, [&](int part) {
             const uint32_t a = std::min<uint32_t>(nr, (uint32_t)part * per), b2 = std::min<uint32_t>(nr, a + per);
+            uint64_t sum = 0; int err = 0;
             for (uint32_t r = a; r < b2; ++r) {
-                const uint8_t* src = bases + offsets[r0 + r];
-                const uint64_t len = st.pin_len[r];
-                uint8_t* dst = st.pin_bases + st.pin_offsets[r];
-                if (len <= keep) { memcpy(dst, src, len); continue; }
-                memcpy(dst, src, n);
-                if (both) memcpy(dst + n, src + len - n, n);
+                const uint64_t x = offsets[r0 + r], y = offsets[r0 + r + 1];
+                if (y < x) { err = 1; break; }
+                const uint64_t len = y - x;
+                if (len > 0xFFFFFFFFull) { err = 2; break; }
+                sum += len <= keep ? len : keep;
+            }
+            part_total[part] = sum; part_err[part] = err;
+        });
+        uint64_t total = 0;
+        for (int q = 0; q < parts; ++q) {
+            if (part_err[q] == 1) rc = set_err(QCAT_ERR_ARG, "offsets must be non-decreasing");
+            else if (part_err[q] == 2) rc = set_err(QCAT_ERR_UNSUPPORTED, "read longer than 4 Gb");
+            const uint64_t t = part_total[q]; part_total[q] = total; total += t;
+        }
+        if (rc) break;
+        st.pin_offsets[0] = 0;
+        t_prefix += now() - t0; t0 = now();
+        p->pool->run(parts, [&](int part) {
+            const uint32_t a = std::min<uint32_t>(nr, (uint32_t)part * per), b2 = std::min<uint32_t>(nr, a + per);
+            uint64_t pos = part_total[part];
+            for (uint32_t r = a; r < b2; ++r) {
+                const uint64_t x = offsets[r0 + r];
+                const uint64_t len = offsets[r0 + r + 1] - x;
+                const uint8_t* src = bases + x;
+                uint8_t* dst = st.pin_bases + pos;
+                st.pin_len[r] = (uint32_t)len;
+                if (len <= keep) { memcpy(dst, src, len); pos += len; }
+                else { memcpy(dst, src, n); if (both) memcpy(dst + n, src + len - n, n); pos += keep; }
+                st.pin_offsets[r + 1] = pos;
             }
         });
-        if (ci >= 2) HIPCHK(hipStreamWaitEvent(p->copy, st.scanned, 0));   // this slot's device buffers are free again
+        t_compact += now() - t0; t0 = now();
+        // this slot's device buffers are free again once the scan of chunk ci - 2 is done: waited for on the HOST, so
+        // that the copy stream never holds a barrier packet behind which its copies would queue up
+        if (ci >= 2) HIPCHK(hipEventSynchronize(st.scanned));
         if (total) HIPCHK(hipMemcpyAsync(st.dev_bases_alloc + BATCH_SLACK, st.pin_bases, total, hipMemcpyHostToDevice, p->copy));
         HIPCHK(hipMemcpyAsync(st.dev_offsets, st.pin_offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, p->copy));
         HIPCHK(hipMemcpyAsync(st.dev_len, st.pin_len, (size_t)nr * 4, hipMemcpyHostToDevice, p->copy));
@@ -945,9 +977,15 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
         if (rc) break;
         HIPCHK(hipMemcpyAsync(p->pin_results + r0, c->results, (size_t)nr * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(st.scanned, c->stream));
+        t_enqueue += now() - t0;
     }
+    const double t_loop = now();
     hipError_t es = hipStreamSynchronize(c->stream);
     hipError_t ec = hipStreamSynchronize(p->copy);
+    if (trace)
+        fprintf(stderr, "[qcat pipeline] %u reads, %u chunks, %u threads: staging wait %.2f ms, prefix %.2f, compaction %.2f, enqueue %.2f, "
+                        "drain %.2f, total so far %.2f ms\n", n_reads, n_chunks, p->pool->size(), t_wait, t_prefix, t_compact, t_enqueue,
+                now() - t_loop, now() - t_begin);
     c->last_n_reads = 0;                                 // the context's result buffer holds the last chunk only
     if (rc) return rc;
     if (es != hipSuccess || ec != hipSuccess)

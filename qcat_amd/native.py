@@ -11,7 +11,7 @@ import threading
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MODE_EPI2ME, MODE_DUAL = 0, 1
 ENDS_5P, ENDS_BOTH = 1, 3
 MAX_TEMPLATES = 16
@@ -43,7 +43,8 @@ class KitDesc(C.Structure):
                 ("min_quality", C.c_double), ("conflict_min_score", C.c_double),
                 ("region_min_adapter_score", C.c_double),
                 ("n_barcode_slots", C.c_int32), ("n_kit_slots", C.c_int32),
-                ("scan_middle_adapter", C.c_int32), ("middle_min_score", C.c_double)]
+                ("scan_middle_adapter", C.c_int32), ("middle_min_score", C.c_double),
+                ("min_read_length", C.c_int32), ("trim_reads", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -83,7 +84,7 @@ class KitDescriptor(object):
     """
 
     def __init__(self, layouts, qcat_config, mode="epi2me", min_quality=None, ends=ENDS_BOTH,
-                 scan_middle=False):
+                 scan_middle=False, min_read_length=0, trim=False):
         if mode not in ("epi2me", "dual"):
             raise RuntimeError("Invalid demultiplexing mode: {}".format(mode))
         if len(layouts) > MAX_TEMPLATES:
@@ -159,13 +160,17 @@ class KitDescriptor(object):
         d.n_kit_slots = len(self.kit_names)
         d.scan_middle_adapter = 1 if scan_middle else 0
         d.middle_min_score = 50.0
+        # the driver's min-length filter of the count histogram (qcat/cli.py:521-534); 0 = count every read
+        d.min_read_length = max(0, int(min_read_length))
+        d.trim_reads = 1 if trim else 0
         self.scan_middle = bool(scan_middle)
         self.desc = d
 
     @property
     def n_count_buckets(self):
         nb = len(self.slot_ids)
-        return (nb * nb if self.mode == "dual" else nb) + 1 + len(self.kit_names) + 1
+        # [barcode slots.., none][kit slots.., none][skipped]
+        return (nb * nb if self.mode == "dual" else nb) + 1 + len(self.kit_names) + 1 + 1
 
     def byref(self):
         return C.byref(self.desc)

@@ -76,7 +76,8 @@ class BarcodeScanner(object):
         raise NotImplementedError("Abstract class")
 
     # -- native plumbing ------------------------------------------------------------------------
-    def descriptor(self, layouts=None, qcat_config=None, ends=native.ENDS_BOTH, scan_middle=None):
+    def descriptor(self, layouts=None, qcat_config=None, ends=native.ENDS_BOTH, scan_middle=None,
+                   min_read_length=0, trim=False):
         """KitDescriptor for ``layouts`` (default: this scanner's) -- also used by the tests to
         drive the CPU oracle with exactly the product's descriptor."""
         if qcat_config is None:
@@ -86,7 +87,8 @@ class BarcodeScanner(object):
         if scan_middle is None:
             scan_middle = self.scan_middle_adapter and ends == native.ENDS_BOTH
         return native.KitDescriptor(layouts, qcat_config, mode=self._native_mode,
-                                    min_quality=self.min_quality, ends=ends, scan_middle=scan_middle)
+                                    min_quality=self.min_quality, ends=ends, scan_middle=scan_middle,
+                                    min_read_length=min_read_length, trim=trim)
 
     def _native_kit(self, layouts, qcat_config, ends):
         key = (tuple(id(l) for l in layouts), qcat_config.fingerprint(), ends, self.min_quality,

@@ -133,3 +133,39 @@ def long_scan_inputs(entry, layouts):
         seqs.append(s)
     chim = [base[i] + base[i + 6] for i in range(6)] + base[:3] + [base[0][:300], base[1][:301], ""]
     return seqs, chim
+
+
+def driver_histogram(desc, layouts, recs, read_lengths, min_read_length, trim):
+    """The count vector the reference DRIVER would accumulate for these records (qcat/cli.py:515-534 +
+    :366-383), restated with Python slicing: trim, drop reads under the min-length filter into
+    `skipped`, count the rest by barcode and by kit.  Layout: [barcodes.., none][kits.., none][skipped]."""
+    nb, nk = len(desc.slot_ids), len(desc.kit_names)
+    dual = desc.mode == "dual"
+    nbc = nb * nb if dual else nb
+    cnt = np.zeros(desc.n_count_buckets, dtype=np.int64)
+    for rec, n in zip(recs, read_lengths):
+        sequence = "x" * int(n)
+        if trim:
+            sequence = sequence[int(rec["trim5p"]):int(rec["trim3p"])]
+        if len(sequence) < min_read_length:
+            cnt[-1] += 1
+            continue
+        slot = nbc
+        if rec["barcode_idx"] >= 0:
+            lay = layouts[rec["adapter_idx"]]
+            slot = desc.id_slots[lay.get_barcode_set(0)[rec["barcode_idx"]].id]
+            if dual:
+                slot = slot * nb + desc.id_slots[lay.get_barcode_set(1)[rec["barcode2_idx"]].id]
+        cnt[slot] += 1
+        cnt[nbc + 1 + (desc.kit_slots[layouts[rec["adapter_idx"]].kit] if rec["adapter_idx"] >= 0 else nk)] += 1
+    return cnt
+
+
+def median_kept_length(det, reads, trim):
+    """median length of the (trimmed) reads under the oracle: a min-length threshold that splits the batch"""
+    import oracle_lib
+    recs = oracle_lib.scan(det.descriptor(), reads, threads=8)
+    lens = np.array([len(r) for r in reads], dtype=np.int64)
+    if trim:
+        lens = np.maximum(np.minimum(recs["trim3p"], lens) - np.minimum(recs["trim5p"], lens), 0)
+    return int(np.median(lens))

@@ -36,7 +36,7 @@ def test_kit_create_validates_without_a_device():
     hip = native.HipLibrary.get()
     det = scanner.factory(kit="PBC096")
     kit = native.NativeKit(det.descriptor())         # host-side preparation only
-    assert hip.lib.qcat_kit_count_buckets(kit.handle) == det.descriptor().n_count_buckets == 96 + 1 + 1 + 1
+    assert hip.lib.qcat_kit_count_buckets(kit.handle) == det.descriptor().n_count_buckets == 96 + 1 + 1 + 1 + 1
     bad = det.descriptor()
     bad.desc.abi_version = 99
     with pytest.raises(RuntimeError, match="ABI version"):

@@ -65,7 +65,7 @@ def histogram_from_records(desc, layouts, recs):
         slots[m] = slot_tables[t][recs["barcode_idx"][m]]
     cnt[:nb + 1] = np.bincount(slots, minlength=nb + 1)
     ks = np.where(recs["adapter_idx"] >= 0, kit_slot[np.maximum(recs["adapter_idx"], 0)], nk)
-    cnt[nb + 1:] = np.bincount(ks, minlength=nk + 1)
+    cnt[nb + 1:nb + 1 + nk + 1] = np.bincount(ks, minlength=nk + 1)       # (last bucket: [skipped], 0 without a filter)
     return cnt
 
 
@@ -83,7 +83,7 @@ def dual_histogram_from_records(desc, layouts, recs):
     cnt[:nb * nb + 1] = np.bincount(slots, minlength=nb * nb + 1)
     kit_slot = np.array([desc.kit_slots[lay.kit] for lay in layouts])
     ks = np.where(recs["adapter_idx"] >= 0, kit_slot[np.maximum(recs["adapter_idx"], 0)], nk)
-    cnt[nb * nb + 1:] = np.bincount(ks, minlength=nk + 1)
+    cnt[nb * nb + 1:nb * nb + 1 + nk + 1] = np.bincount(ks, minlength=nk + 1)
     return cnt
 
 
@@ -98,7 +98,7 @@ def test_config2_one_million_reads_5p_only():
     r = Resident(det, native.ENDS_5P, 1000000, 20260929, 0.08)
     try:
         recs, cnt = r.scan()
-        assert cnt[:13].sum() == r.n and cnt[13:].sum() == r.n
+        assert cnt[:13].sum() == r.n and cnt[13:15].sum() == r.n and cnt[15] == 0
         assert np.array_equal(cnt, histogram_from_records(r.desc, det.layouts, recs))
         recs2, cnt2 = r.scan()
         assert recs2.tobytes() == recs.tobytes() and np.array_equal(cnt, cnt2)          # idempotence
@@ -174,7 +174,7 @@ def test_config5_dual_one_million_reads(which, tmp_path):
         assert info["packed"] == 1 and info["n_static_groups"] == info["n_groups"] == 4      # static-letter kernels either way
         recs, cnt = r.scan()
         nb = len(r.desc.slot_ids)
-        assert cnt[:nb * nb + 1].sum() == r.n and cnt[nb * nb + 1:].sum() == r.n            # histogram = records
+        assert cnt[:nb * nb + 1].sum() == r.n and cnt[nb * nb + 1:-1].sum() == r.n and cnt[-1] == 0            # histogram = records
         assert np.array_equal(cnt, dual_histogram_from_records(r.desc, det.layouts, recs))
         recs2, cnt2 = r.scan()
         assert recs2.tobytes() == recs.tobytes() and np.array_equal(cnt, cnt2)              # idempotence

@@ -119,6 +119,6 @@ def test_dual_96x96_custom_kit(tmp_path):
     det = scanner.factory(mode="dual", kit_folder=folder)
     assert [len(l.barcode_set_1) for l in det.layouts] == [96, 96]
     d = det.descriptor()
-    assert d.n_count_buckets == 96 * 96 + 1 + 1 + 1
+    assert d.n_count_buckets == 96 * 96 + 1 + 1 + 1 + 1
     reads = random_reads(rng, det.layouts, 300, 1, 0)
     compare(det, config.qcatConfig(), reads)

@@ -318,6 +318,33 @@ def test_host_buffer_scan_pipeline_equals_one_shot_and_oracle(kit_name, mode, en
     assert small.tobytes() == want[:5000].tobytes()
 
 
+@pytest.mark.parametrize("mode,kit,min_len,trim,middle", [("epi2me", "PBC096", 100, True, False), ("epi2me", "PBC096", "median", True, False),
+                                                          ("epi2me", "PBC096", "median", False, False), ("dual", None, "median", True, False),
+                                                          ("epi2me", "NBD103/NBD104", "median", True, True)])
+def test_skipped_bucket_on_the_device(mode, kit, min_len, trim, middle):
+    """the device histogram applies the driver's min-length filter (qcat/cli.py:521-534) exactly like the
+    oracle and like a Python restatement of the driver loop -- resident scans, host-buffer scans (one-shot
+    and pipelined), and the k_count path of --detect-middle."""
+    det = scanner.factory(mode=mode, kit=kit, scan_middle_adapter=middle)
+    reads = synth.synth_batch(40000, 909, det.layouts, 1, 0, error_rate=0.08)
+    for i in range(0, 4000, 7):
+        reads[i] = reads[i][:60 + (i * 13) % 800]
+    reads[5], reads[6] = "", "ACGT" * 30
+    if min_len == "median":
+        min_len = helpers.median_kept_length(det, reads[:2000], trim)
+    d = det.descriptor(min_read_length=min_len, trim=trim)
+    kit_h = native.NativeKit(d)
+    cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+    recs = native.NativeContext(0).scan(kit_h, *native.pack_reads(reads), counts=cnt)
+    o_recs, o_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
+    assert recs.tobytes() == o_recs.tobytes() and np.array_equal(cnt, o_cnt)
+    assert np.array_equal(cnt, helpers.driver_histogram(d, det.layouts, recs, [len(r) for r in reads], min_len, trim))
+    assert 0 < cnt[-1] < len(reads)
+    cnt2 = np.zeros(d.n_count_buckets, dtype=np.int64)
+    native.NativeContext(0).scan(kit_h, *native.pack_reads(reads[:3000]), counts=cnt2)       # one-shot path
+    assert np.array_equal(cnt2, oracle_lib.scan(d, reads[:3000], counts=True, threads=8)[1])
+
+
 def test_timing_ring_and_stream_accessor():
     """qcat_ctx_last_timing averages over the scans since the previous call (no sync between scans);
     qcat_ctx_stream hands out the context's stream for stream-ordered RCCL calls."""

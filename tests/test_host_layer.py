@@ -124,7 +124,7 @@ def test_descriptor_flattening():
     t = d.desc.templates[0]
     assert (t.length, t.is_double_barcode, t.bc_start[0], t.bc_end[0], t.bc_start[1], t.bc_end[1]) == (83, 1, 6, 29, 45, 68)
     assert (t.sets[0].n, t.sets[1].n, t.sets[0].barcode_len) == (24, 96, 24)
-    assert d.desc.n_barcode_slots == 96 and d.n_count_buckets == 96 * 96 + 1 + 1 + 1
+    assert d.desc.n_barcode_slots == 96 and d.n_count_buckets == 96 * 96 + 1 + 1 + 1 + 1
     e = scanner.factory(kit="RPB004/RLB001").descriptor()           # id 12 appears twice (barcode12, barcode12a)
     ids = [e.desc.templates[0].sets[0].ids[i] for i in range(13)]
     assert ids[11] == ids[12] and len(set(ids)) == 12

@@ -117,3 +117,25 @@ def test_scan_of_long_sequences(i):
     recs = oracle_lib.scan_sequences(det.descriptor(ends=native.ENDS_5P), seqs)
     for rec, want in zip(recs, entry["scan"]):
         assert helpers.record_as_golden(rec, det.layouts, entry["mode"]) == want
+
+
+@pytest.mark.parametrize("mode,kit,min_len,trim", [("epi2me", "PBC096", 100, True), ("epi2me", "PBC096", "median", True),
+                                                   ("epi2me", "PBC096", "median", False), ("dual", None, "median", True),
+                                                   ("epi2me", "NBD103/NBD104", 0, True)])
+def test_skipped_bucket_follows_the_driver(mode, kit, min_len, trim):
+    """[skipped] bucket of the count vector = the reference driver's min-length filter applied after
+    trimming (qcat/cli.py:521-534): oracle counts vs a Python restatement of that loop."""
+    det = scanner.factory(mode=mode, kit=kit)
+    reads = synth.synth_batch(300, 808, det.layouts, 1, 0, error_rate=0.08)
+    reads += [r[:k] for r, k in zip(reads[:40], range(60, 860, 20))] + ["", "ACGT" * 30]
+    if min_len == "median":                                   # a threshold that splits the batch
+        min_len = helpers.median_kept_length(det, reads, trim)
+    d = det.descriptor(min_read_length=min_len, trim=trim)
+    recs, cnt = oracle_lib.scan(d, reads, counts=True)
+    want = helpers.driver_histogram(d, det.layouts, recs, [len(r) for r in reads], min_len, trim)
+    assert np.array_equal(cnt, want)
+    assert cnt.sum() - cnt[-1] == 2 * (len(reads) - cnt[-1])        # every kept read: one barcode + one kit bucket
+    if min_len >= 300:
+        assert 0 < cnt[-1] < len(reads)
+    if min_len == 0:
+        assert cnt[-1] == 0
