@@ -55,7 +55,13 @@ typedef enum qcat_status {
 /* Scanner mode: which `scan()` the batch entry points reproduce. */
 typedef enum qcat_mode {
     QCAT_MODE_EPI2ME = 0,   /* qcat/scanner_epi2me.py:33-144 */
-    QCAT_MODE_DUAL = 1      /* qcat/scanner_dual.py:35-146   */
+    QCAT_MODE_DUAL = 1,     /* qcat/scanner_dual.py:35-146   */
+    /* qcat/scanner_simple.py:41-91: no adapter templates -- every barcode of ONE list is aligned to the whole
+     * window (find_highest_scoring_barcode without contexts, scanner_base.py:63-141), the winner is reported when
+     * its score reaches min_quality, `adapter` is None and adapter_end is the winner's end_query.  The descriptor
+     * carries one template of length 0 whose sets[0] is the barcode list (bc_len[0] = barcode length,
+     * bc_start / bc_end = -1); general int32 kernel. */
+    QCAT_MODE_SIMPLE = 2
 } qcat_mode;
 
 /* Which read ends are scanned. */

@@ -155,6 +155,10 @@ void qo_kit_free(qo_kit* k) {
 
 int qo_kit_prepare(const qcat_kit_desc* d, qo_kit** out) {
     qo_init_tables();
+    if (d && d->mode == QCAT_MODE_SIMPLE && (d->n_templates != 1 || d->templates[0].length != 0)) {
+        snprintf(qo_err, sizeof qo_err, "simple mode takes one empty template holding the barcode list");
+        return QCAT_ERR_ARG;
+    }
     if (!d || d->abi_version != QCAT_ABI_VERSION || d->n_templates < 0 ||
         d->n_templates > QCAT_MAX_TEMPLATES) {
         snprintf(qo_err, sizeof qo_err, "qo_kit_prepare: bad descriptor");
@@ -165,7 +169,8 @@ int qo_kit_prepare(const qcat_kit_desc* d, qo_kit** out) {
     for (int t = 0; t < k->nt; ++t) {
         const qcat_template_desc* s = &d->templates[t];
         qo_tpl* p = &k->tpl[t];
-        if (s->length <= 0 || s->length > QCAT_MAX_TEMPLATE_LEN) {
+        const int simple = d->mode == QCAT_MODE_SIMPLE;
+        if ((simple ? s->length != 0 : s->length <= 0) || s->length > QCAT_MAX_TEMPLATE_LEN) {
             snprintf(qo_err, sizeof qo_err, "template %d: bad length %d", t, s->length);
             qo_kit_free(k); return QCAT_ERR_ARG;
         }
@@ -176,7 +181,7 @@ int qo_kit_prepare(const qcat_kit_desc* d, qo_kit** out) {
             p->bc_start[i] = s->bc_start[i]; p->bc_end[i] = s->bc_end[i]; p->bc_len[i] = s->bc_len[i];
             bc_total += s->bc_len[i];
         }
-        p->den = (p->len - bc_total) * d->match + bc_total * d->nmatch;
+        p->den = simple ? 1 : (p->len - bc_total) * d->match + bc_total * d->nmatch;
         if (p->den == 0) {
             snprintf(qo_err, sizeof qo_err, "template %d: zero normalisation denominator", t);
             qo_kit_free(k); return QCAT_ERR_ARG;
@@ -354,13 +359,44 @@ static qo_scan qo_scan_end(const qo_kit* k, const uint8_t* w, int L, qcat_end_tr
     return r;
 }
 
+/* BarcodeScannerSimple.scan, qcat/scanner_simple.py:41-91: find_highest_scoring_barcode(window, self.barcodes,
+ * compute_identity=True) -- every barcode against the WHOLE window, no contexts.  The function returns
+ * (max_barcode, q_score, max_score, max_end) (scanner_base.py:141), so the value scan() calls `identity` and
+ * compares with min_quality is the normalised SCORE; the matches/length statistics of sg_stats never leave
+ * find_highest_scoring_barcode.  adapter is None, adapter_end = end_query of the winner's alignment. */
+static qo_scan qo_scan_simple(const qo_kit* k, const uint8_t* w, int L, qcat_end_trace* tr, int16_t* rows) {
+    const qo_set* s = &k->tpl[0].sets[0];
+    int best = -1, best_raw = 0, best_end = -1;
+    if (L > 0) {
+        for (int b = 0; b < s->n; ++b) {
+            qo_align a;
+            qo_sg_codes(w, L, s->targets + (size_t)b * s->tlen, s->tlen, 1, 1, k->d.barcode_matrix, &a);
+            if (rows) rows[b] = (int16_t)a.score;
+            if (best < 0 || best_raw == 0 || best_raw < a.score) { best = b; best_raw = a.score; best_end = a.end_query; }
+        }
+    }
+    qo_scan r = qo_empty();
+    double score = best >= 0 ? best_raw * 100.0 / (1.0 * s->tlen) : 0.0;
+    if (!(score < k->d.min_quality)) {                       /* `if identity < self.min_quality: return empty` */
+        r.has_barcode = best >= 0; r.bc[0] = best; r.raw = best >= 0 ? best_raw : 0; r.den = best >= 0 ? s->tlen : 1;
+        r.score = score; r.adapter = -1; r.adapter_end = best_end; r.exit_status = 0;
+    }
+    if (tr) {
+        tr->window_len = L; tr->best_tpl = -1; tr->best_end = best_end; tr->best_raw = -1; tr->used_tpl = 0;
+        tr->region_path = 0; tr->region_start[0] = 0; tr->region_len[0] = L;
+        tr->bc_idx[0] = best; tr->bc_raw[0] = best_raw; tr->bc_idx[1] = -1;
+        tr->adapter_end = r.adapter_end;
+    }
+    return r;
+}
+
 static int qo_same_id(const qo_kit* k, const qo_scan* a, const qo_scan* b) {
     /* barcode.id equality; dual ids are "id1/id2" strings (scanner_dual.py:131-134) */
     for (int s = 0; s < 2; ++s) {
         if (a->bc[s] < 0 && b->bc[s] < 0) continue;
         if (a->bc[s] < 0 || b->bc[s] < 0) return 0;
-        int ia = k->tpl[a->adapter].sets[s].ids[a->bc[s]];
-        int ib = k->tpl[b->adapter].sets[s].ids[b->bc[s]];
+        int ia = k->tpl[a->adapter < 0 ? 0 : a->adapter].sets[s].ids[a->bc[s]];     /* (simple mode: adapter None) */
+        int ib = k->tpl[b->adapter < 0 ? 0 : b->adapter].sets[s].ids[b->bc[s]];
         if (ia != ib) return 0;
     }
     return 1;
@@ -424,8 +460,9 @@ static void qo_detect_barcode(const qo_kit* k, const uint8_t* read, int64_t len,
                               qcat_result* o, qcat_end_trace* tr, int16_t* rows, uint32_t stride) {
     uint8_t w[QCAT_MAX_WINDOW];
     int n = k->d.max_align_length;
+    const int simple = k->d.mode == QCAT_MODE_SIMPLE;
     int L = qo_window(read, len, 0, n, w);
-    qo_scan r5 = qo_scan_end(k, w, L, tr, rows, stride);
+    qo_scan r5 = simple ? qo_scan_simple(k, w, L, tr, rows) : qo_scan_end(k, w, L, tr, rows, stride);
     if (k->d.ends == QCAT_ENDS_5P) {           /* config 2: scan() of the 5' window only */
         qo_to_record(&r5, 0, 0, o);
         return;
@@ -433,7 +470,8 @@ static void qo_detect_barcode(const qo_kit* k, const uint8_t* read, int64_t len,
     int trim5 = r5.adapter_end > 0 ? r5.adapter_end : 0;
     if (r5.score < k->d.min_quality) r5 = qo_empty();
     L = qo_window(read, len, 1, n, w);
-    qo_scan r3 = qo_scan_end(k, w, L, tr ? tr + 1 : NULL, rows ? rows + 2 * stride : NULL, stride);
+    qo_scan r3 = simple ? qo_scan_simple(k, w, L, tr ? tr + 1 : NULL, rows ? rows + 2 * stride : NULL)
+                        : qo_scan_end(k, w, L, tr ? tr + 1 : NULL, rows ? rows + 2 * stride : NULL, stride);
     int64_t trim3 = len;
     if (r3.adapter >= 0 && r3.adapter_end > 0) trim3 -= r3.adapter_end;
     if (r3.score < k->d.min_quality) r3 = qo_empty();
@@ -470,8 +508,8 @@ static void qo_count(const qo_kit* k, const qcat_result* r, int64_t len, int64_t
         if (len < k->d.min_read_length) { counts[nbuckets + 1 + nk + 1] += 1; return; }   /* skipped_reads += 1; continue */
     }
     int slot = nbuckets;                                    /* "none" */
-    if (r->barcode_idx >= 0 && r->adapter_idx >= 0) {
-        const qo_tpl* p = &k->tpl[r->adapter_idx];
+    if (r->barcode_idx >= 0 && (r->adapter_idx >= 0 || k->d.mode == QCAT_MODE_SIMPLE)) {
+        const qo_tpl* p = &k->tpl[r->adapter_idx < 0 ? 0 : r->adapter_idx];
         slot = p->sets[0].ids[r->barcode_idx];
         if (k->d.mode == QCAT_MODE_DUAL) slot = slot * nb + p->sets[1].ids[r->barcode2_idx];
     }
@@ -530,7 +568,7 @@ int qo_scan_sequences(const qcat_kit_desc* d, const uint8_t* bases, const uint64
         int64_t len = (int64_t)(offsets[r + 1] - offsets[r]);
         uint8_t* w = (uint8_t*)malloc((size_t)len + 1);
         for (int64_t i = 0; i < len; ++i) w[i] = qo_code_of[seq[i]];
-        qo_scan s = qo_scan_end(k, w, (int)len, NULL, NULL, 0);
+        qo_scan s = d->mode == QCAT_MODE_SIMPLE ? qo_scan_simple(k, w, (int)len, NULL, NULL) : qo_scan_end(k, w, (int)len, NULL, NULL, 0);
         qo_to_record(&s, 0, 0, &out[r]);
         free(w);
     }

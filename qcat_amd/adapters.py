@@ -19,6 +19,8 @@ from collections import namedtuple
 from .layout import AdapterLayout
 
 Barcode = namedtuple("Barcode", "name id sequence fwd_strand")
+_Placeholder = namedtuple("_Placeholder", "start end")
+NO_PLACEHOLDER = _Placeholder(-1, -1)      # what AdapterLayout keeps for a barcode set that does not exist
 
 KIT_BUNDLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "resources", "kits.json")
 KIT_FOLDER = KIT_BUNDLE      # name kept for callers that print it
@@ -87,6 +89,27 @@ def _bundle_entries():
             if data[key] is not None:
                 data[key] = [dict(zip(Barcode._fields, row)) for row in data[key]]
         yield data
+
+
+def get_barcodes_from_fastq(reads_fa):
+    """Barcode list from a FASTA file, ids 1.. in file order (``qcat/adapters.py:108-118``)."""
+    barcodes, title, seq = [], None, []
+
+    def flush():
+        if title is not None:
+            barcodes.append(read_barcode({"name": title, "id": len(barcodes) + 1, "sequence": "".join(seq)}))
+    with open(reads_fa) as fh:
+        for line in fh:
+            line = line.rstrip("\n")
+            if line.startswith(">"):
+                flush()
+                title, seq = line[1:].rstrip(), []
+            elif title is not None:
+                seq.append(line.strip())
+    flush()
+    if len(barcodes) <= 0:
+        logging.error("Couldn't find barcodes in {}".format(reads_fa))
+    return barcodes
 
 
 def get_barcodes_simple(kit="standard", filename=None):

@@ -33,7 +33,7 @@ def get_mode(args):
     if args.MODE_DUAL:
         return "dual"
     if args.MODE_SIMPLE:
-        raise ValueError("simple mode is outside the MI355X hot path (testing/debug mode of the reference)")
+        return "simple"
     return "epi2me"
 
 
@@ -67,11 +67,16 @@ def parse_args(argv):
     m.add_argument("--guppy", dest="MODE_GUPPY", action="store_true")
     m.add_argument("--epi2me", dest="MODE_EPI2ME", action="store_true", help="Use EPI2ME's demultiplexing algorithm (default)")
     m.add_argument("--dual", dest="MODE_DUAL", action="store_true", help="Use dual barcoding algorithm")
-    m.add_argument("--simple", dest="MODE_SIMPLE", action="store_true")
+    m.add_argument("--simple", dest="MODE_SIMPLE", action="store_true",
+                   help="Use simple demultiplexing algorithm. Only looks for barcodes, not for adapter sequences. "
+                        "Use only for testing purposes!")
     e = p.add_argument_group("EPI2ME options (only valid with --epi2me)")
     e.add_argument("--no-batch", dest="nobatch", action="store_true", help="Don't use information from multiple reads for kit detection")
     e.add_argument("--filter-barcodes", dest="FILTER_BARCODES", action="store_true",
                    help="Filter rare barcode calls when run in batch mode")
+    sg = p.add_argument_group("Simple options (only valid with --simple)")
+    sg.add_argument("--simple-barcodes", dest="SIMPLE_BARCODES", default="standard",
+                    help="Use 12 (standard) or 96 (extended) barcodes for demultiplexing")
     p.add_argument("--device", dest="device", type=int, default=0, help="GPU index")
     return p.parse_args(argv)
 
@@ -271,7 +276,8 @@ def main(argv=None):
                     logging.info("{:<30}{}".format(kit, kits[kit]))
             return
         start = time.time()
-        qcat_cli(reads_fq=args.fastq, kit=args.kit, mode=get_mode(args), nobatch=args.nobatch, out=args.barcode_dir,
+        mode = get_mode(args)
+        qcat_cli(reads_fq=args.fastq, kit=args.SIMPLE_BARCODES if mode == "simple" else args.kit, mode=mode, nobatch=args.nobatch, out=args.barcode_dir,
                  min_qual=args.min_qual, tsv=args.tsv, output=args.output, threads=args.threads, trim=args.TRIM,
                  adapter_yaml=None, quiet=args.QUIET, filter_barcodes=args.FILTER_BARCODES,
                  middle_adapter=args.DETECT_MIDDLE, min_read_length=args.min_length,

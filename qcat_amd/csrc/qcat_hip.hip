@@ -492,9 +492,15 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         mark(c, "k_pack_windows");
     }
     const bool use_packed = hk.fast_ok && !c->force_generic && packed_supported(hk);
+    if (hk.mode == QCAT_MODE_SIMPLE && adapter_only) return set_err(QCAT_ERR_ARG, "simple mode has no adapter templates to vote with");
     if (resume_kit_mask >= 0 && !(use_packed && c->packed.slices_single))
         return set_err(QCAT_ERR_UNSUPPORTED, "the adapter pass of this kit cannot be resumed per kit (table or general kernels)");
-    if (use_packed) {
+    if (hk.mode == QCAT_MODE_SIMPLE) {
+        uint32_t blocks = (uint32_t)((n_ends + GEN_THREADS - 1) / GEN_THREADS);
+        hipLaunchKernelGGL(k_scan_simple, dim3(blocks), dim3(GEN_THREADS), 0, c->stream, kp, c->win, c->wlen, (uint32_t)n_ends, c->recs,
+                           (debug && row_stride) ? c->dbg_rows : nullptr, row_stride);
+        mark(c, "k_scan_simple");
+    } else if (use_packed) {
         rc = packed_scan(c->stream, kp, hk, c->win, c->wlen, (uint32_t)n_ends, c->recs, &c->packed,
                          debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride,
                          [&](const char* nm) { mark(c, nm); }, adapter_only, resume_kit_mask);
@@ -835,6 +841,8 @@ static void fill_trace(const HostKit& hk, const EndRec& r, const int32_t* tplraw
     if (hk.dk.mode == QCAT_MODE_EPI2ME) {
         int ae = r.best_end + p.trim_offset;
         t->adapter_end = ae > r.window_len ? r.window_len : ae;
+    } else if (hk.dk.mode == QCAT_MODE_SIMPLE) {
+        t->adapter_end = (r.bc_idx[0] >= 0 && r.bc_raw[0] >= p.sets[0].min_raw_pass) ? r.best_end : 0;
     } else {
         t->adapter_end = (r.bc_idx[0] >= 0 && r.bc_idx[1] >= 0) ? r.best_end : 0;
     }

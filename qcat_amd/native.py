@@ -12,7 +12,7 @@ import threading
 import numpy as np
 
 ABI_VERSION = 3
-MODE_EPI2ME, MODE_DUAL = 0, 1
+MODE_EPI2ME, MODE_DUAL, MODE_SIMPLE = 0, 1, 2
 ENDS_5P, ENDS_BOTH = 1, 3
 MAX_TEMPLATES = 16
 
@@ -85,7 +85,7 @@ class KitDescriptor(object):
 
     def __init__(self, layouts, qcat_config, mode="epi2me", min_quality=None, ends=ENDS_BOTH,
                  scan_middle=False, min_read_length=0, trim=False):
-        if mode not in ("epi2me", "dual"):
+        if mode not in ("epi2me", "dual", "simple"):
             raise RuntimeError("Invalid demultiplexing mode: {}".format(mode))
         if len(layouts) > MAX_TEMPLATES:
             raise RuntimeError("too many adapter templates: {} > {}".format(len(layouts), MAX_TEMPLATES))
@@ -93,7 +93,7 @@ class KitDescriptor(object):
         self.mode = mode
         self.ends = ends
         if min_quality is None:
-            min_quality = 58 if mode == "epi2me" else 60
+            min_quality = 58 if mode == "epi2me" else 60       # (dual and simple: 60)
         self.min_quality = min_quality
         self._keep = []
         self.id_slots = {}          # Barcode.id -> slot
@@ -140,7 +140,7 @@ class KitDescriptor(object):
 
         d = KitDesc()
         d.abi_version = ABI_VERSION
-        d.mode = MODE_DUAL if mode == "dual" else MODE_EPI2ME
+        d.mode = {"epi2me": MODE_EPI2ME, "dual": MODE_DUAL, "simple": MODE_SIMPLE}[mode]
         d.ends = ends
         d.n_templates = len(self.layouts)
         d.templates = C.cast(tarr, C.POINTER(TemplateDesc))

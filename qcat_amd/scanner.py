@@ -7,8 +7,9 @@ from . import adapters
 from .scanner_base import BarcodeScanner
 from .scanner_epi2me import BarcodeScannerEPI2ME
 from .scanner_dual import BarcodeScannerDual
+from .scanner_simple import BarcodeScannerSimple
 
-__all__ = ["BarcodeScanner", "BarcodeScannerEPI2ME", "BarcodeScannerDual", "factory",
+__all__ = ["BarcodeScanner", "BarcodeScannerEPI2ME", "BarcodeScannerDual", "BarcodeScannerSimple", "factory",
            "get_modes", "get_kits", "get_kits_info", "get_adapter_by_name"]
 
 

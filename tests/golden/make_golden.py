@@ -134,8 +134,21 @@ def install_standins():
 
             sg = sg_striped_32
 
-            def sg_stats_striped_32(*a, **k):
-                raise NotImplementedError("stats alignments are outside the hot path")
+            class StatsResult(Result):
+                def __init__(self, score, end_query, end_ref, matches, length):
+                    Result.__init__(self, score, end_query, end_ref)
+                    self.matches, self.length = matches, length
+
+            def sg_stats_striped_32(s1, s2, open, extend, matrix):
+                """simple mode (scanner_simple.py:70-74): score / end_query as sg; matches / length for completeness
+                (nothing on the scanner paths consumes them, see sg_independent.sg_stats)"""
+                CALLS["n"] += 1
+                CALLS["cells"] += len(s1) * len(s2)
+                flat, score = matrix.scorer()
+                key = ("stats", s1, s2, open, extend, matrix.alphabet, flat)
+                if key not in _MEMO:
+                    _MEMO[key] = sg_independent.sg_stats(s1, s2, open, extend, score)
+                return StatsResult(*_MEMO[key])
 
             sg_stats = sg_stats_striped_32
             '''))
@@ -240,8 +253,46 @@ def end_to_json(e, keep_rows):
     return out
 
 
+def simple_section(ref_scanner, cfg, fastq, inline, inline_names, seed0):
+    """10. BarcodeScannerSimple (qcat/scanner_simple.py): detect_barcode with the bundled barcode lists over reads
+    that carry PCR barcodes (the lists are the PCR barcode family, both strands)."""
+    out = []
+    lwb = ref_scanner.factory(mode="epi2me", kit="PBK004/LWB001").layouts
+    pbc = ref_scanner.factory(mode="epi2me", kit="PBC096").layouts
+    for which, lays, n in (("standard", lwb, 40), ("extended", pbc, 24)):
+        det = ref_scanner.factory(mode="simple", kit=which)
+        for e in (0.0, 0.1):
+            gen = {"seed": seed0 + 40, "n": n, "tpl_5p": 1, "tpl_3p": 0, "error_rate": e, "kit": lays[0].kit}
+            reads = synth.synth_batch(n, gen["seed"], lays, 1, 0, error_rate=e)
+            extra = ["", "A", reads[0][:100], reads[1][:151], "N" * 200, reads[2].lower()]
+            res = []
+            for r in reads + extra:
+                d = det.detect_barcode(r, qcat_config=cfg)
+                bc = d["barcode"]
+                res.append({"barcode_index": -1 if bc is None else det.barcodes.index(bc),
+                            "barcode_name": None if bc is None else bc.name, "barcode_id": None if bc is None else bc.id,
+                            "score_hex": float(d["barcode_score"]).hex(), "adapter": d["adapter"],
+                            "adapter_end": d["adapter_end"], "trim5p": d["trim5p"], "trim3p": d["trim3p"],
+                            "exit_status": d["exit_status"]})
+            out.append({"list": which, "n_barcodes": len(det.barcodes), "min_quality": det.min_quality, "gen": gen,
+                        "extra": extra, "results": res})
+            print("simple/%s e=%.2f: %d reads, %d called, exits %s" % (which, e, len(res), sum(1 for x in res if x["barcode_name"]),
+                                                                      sorted(set(x["exit_status"] for x in res))))
+    return out
+
+
 def main():
     install_standins()
+    if "--section" in sys.argv and sys.argv[sys.argv.index("--section") + 1] == "simple":
+        ref_scanner, ref_base, ref_epi, ref_dual, ref_config = import_reference()
+        path = os.path.join(HERE, "golden_vectors.json")
+        with open(path) as fh:
+            doc = json.load(fh)
+        doc["simple"] = simple_section(ref_scanner, ref_config.qcatConfig(), None, None, None, 20260928)
+        with open(path, "w") as fh:
+            json.dump(doc, fh, separators=(",", ":"))
+        print("golden_vectors.json:", os.path.getsize(path), "bytes (section simple regenerated)")
+        return
     ref_scanner, ref_base, ref_epi, ref_dual, ref_config = import_reference()
     import parasail
     tracer = Tracer([ref_epi, ref_dual])
@@ -437,12 +488,14 @@ def main():
                           "scan_middle": middles})
         print("long scan %s/%s: %d scans, scan_middle %s" % (mode, kit, len(scans), middles))
 
+    simple = simple_section(ref_scanner, cfg, fastq, inline, inline_names, seed0)
+
     with open(os.path.join(HERE, "golden_vectors.json"), "w") as fh:
         json.dump({"generator": "tests/golden/make_golden.py",
                    "template_order": "sorted by kit file name",
                    "dp": "independent scalar Python DP tests/golden/sg_independent.py (parasail absent; the oracle is not involved) -- see make_golden.py docstring",
                    "cases": cases, "region_table": region_table, "batch": batch,
-                   "batch_fastq": per_file_votes, "middle": middle, "long_scan": long_scan,
+                   "batch_fastq": per_file_votes, "middle": middle, "long_scan": long_scan, "simple": simple,
                    "scan5p": {"kit": "NBD103/NBD104",
                               "gen": {"seed": seed0 + 12, "n": 48, "tpl_5p": 1, "tpl_3p": 0, "error_rate": 0.08,
                                       "no_adapter_fraction": 0.05, "insert_len": 600, "lead_min": 5, "lead_max": 40},

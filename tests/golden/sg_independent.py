@@ -92,3 +92,43 @@ def sg(s1, s2, gap_open, gap_extend, score):
         elif v == best and end_ref == m - 1 and i - 1 < end_query:
             end_query = i - 1
     return best, end_query, end_ref
+
+
+def sg_stats(s1, s2, gap_open, gap_extend, score):
+    """-> (score, end_query, end_ref, matches, length): the same alignment with the number of exact matches and
+    of alignment columns along ONE optimal path (diagonal preferred over a gap in the target, that over a gap in
+    the query -- parasail's own tie order is not documented here and NOTHING on the scanner paths consumes these
+    two numbers: find_highest_scoring_barcode returns the score in their place, qcat/scanner_base.py:141)."""
+    n, m = len(s1), len(s2)
+    best, end_query, end_ref = sg(s1, s2, gap_open, gap_extend, score)
+    # recompute with statistics carried along (small inputs only: the simple-mode fixtures)
+    H = [[0] * (n + 1) for _ in range(m + 1)]
+    E = [[NEG] * (n + 1) for _ in range(m + 1)]
+    F = [[NEG] * (n + 1) for _ in range(m + 1)]
+    MH = [[(0, 0)] * (n + 1) for _ in range(m + 1)]
+    ME = [[(0, 0)] * (n + 1) for _ in range(m + 1)]
+    MF = [[(0, 0)] * (n + 1) for _ in range(m + 1)]
+    for j in range(1, m + 1):
+        b = s2[j - 1]
+        for i in range(1, n + 1):
+            e_ext, e_open = E[j - 1][i] - gap_extend, H[j - 1][i] - gap_open
+            if e_open > e_ext:
+                E[j][i], ME[j][i] = e_open, (MH[j - 1][i][0], MH[j - 1][i][1] + 1)
+            else:
+                E[j][i], ME[j][i] = e_ext, (ME[j - 1][i][0], ME[j - 1][i][1] + 1)
+            f_ext, f_open = F[j][i - 1] - gap_extend, H[j][i - 1] - gap_open
+            if f_open > f_ext:
+                F[j][i], MF[j][i] = f_open, (MH[j][i - 1][0], MH[j][i - 1][1] + 1)
+            else:
+                F[j][i], MF[j][i] = f_ext, (MF[j][i - 1][0], MF[j][i - 1][1] + 1)
+            d = H[j - 1][i - 1] + score(s1[i - 1], b)
+            dm = (MH[j - 1][i - 1][0] + (1 if s1[i - 1].upper() == b.upper() else 0), MH[j - 1][i - 1][1] + 1)
+            h, mh = d, dm
+            if E[j][i] > h:
+                h, mh = E[j][i], ME[j][i]
+            if F[j][i] > h:
+                h, mh = F[j][i], MF[j][i]
+            H[j][i], MH[j][i] = h, mh
+    matches, length = MH[end_ref + 1][end_query + 1]
+    assert H[end_ref + 1][end_query + 1] == best
+    return best, end_query, end_ref, matches, length

@@ -169,3 +169,19 @@ def median_kept_length(det, reads, trim):
     if trim:
         lens = np.maximum(np.minimum(recs["trim3p"], lens) - np.minimum(recs["trim5p"], lens), 0)
     return int(np.median(lens))
+
+
+def simple_reads(entry):
+    """Re-create the reads of one `simple` fixture (make_golden.py section 10)."""
+    g = entry["gen"]
+    lays = scanner.factory(mode="epi2me", kit=g["kit"]).layouts
+    return synth.synth_batch(g["n"], g["seed"], lays, g["tpl_5p"], g["tpl_3p"], error_rate=g["error_rate"]) + entry["extra"]
+
+
+def simple_record_as_golden(rec, barcodes):
+    b = int(rec["barcode_idx"])
+    score = int(rec["raw_score"]) * 100.0 / (1.0 * int(rec["score_den"])) if b >= 0 else 0.0
+    return {"barcode_index": b, "barcode_name": barcodes[b].name if b >= 0 else None,
+            "barcode_id": barcodes[b].id if b >= 0 else None, "score_hex": float(score).hex(),
+            "adapter": None if rec["adapter_idx"] < 0 else "?", "adapter_end": int(rec["adapter_end"]),
+            "trim5p": int(rec["trim5p"]), "trim3p": int(rec["trim3p"]), "exit_status": int(rec["exit_status"])}

@@ -80,7 +80,7 @@ def test_adapter_layout():
 
 
 def test_registry_and_kit_selection():
-    assert scanner.get_modes() == ["epi2me", "dual"]
+    assert scanner.get_modes() == ["epi2me", "dual", "simple"]
     kits = scanner.get_kits()
     assert kits[0] == "Auto" and "PBC096" in kits and len(kits) == 15
     assert scanner.get_kits_info()["PBC096"] == "PCR Barcoding Kit with 96 barcodes"
@@ -94,7 +94,10 @@ def test_registry_and_kit_selection():
     assert [l.kit for l in scanner.factory(mode="dual", kit="PBC096").layouts] == ["DUAL", "DUAL"]   # kit is ignored
     assert scanner.factory(mode="guppy").get_name() == "epi2me"
     with pytest.raises(RuntimeError, match="Invalid demultiplexing mode"):
-        scanner.factory(mode="simple")
+        scanner.factory(mode="brill")
+    simple = scanner.factory(mode="simple", kit="standard")
+    assert simple.get_name() == "simple" and simple.min_quality == 60 and len(simple.barcodes) == 24
+    assert simple.barcode_count() == 25 and len(scanner.factory(mode="simple", kit="extended").barcodes) == 120
 
 
 def test_config_quirks_and_ini_roundtrip(tmp_path):

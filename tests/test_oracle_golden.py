@@ -139,3 +139,15 @@ def test_skipped_bucket_follows_the_driver(mode, kit, min_len, trim):
         assert 0 < cnt[-1] < len(reads)
     if min_len == 0:
         assert cnt[-1] == 0
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_simple_mode(i):
+    """BarcodeScannerSimple (qcat/scanner_simple.py): oracle vs the reference's detect_barcode."""
+    entry = helpers.golden()["simple"][i]
+    det = scanner.factory(mode="simple", kit=entry["list"])
+    assert len(det.barcodes) == entry["n_barcodes"] and det.min_quality == entry["min_quality"] == 60
+    reads = helpers.simple_reads(entry)
+    recs = oracle_lib.scan(det.descriptor(), reads)
+    assert [helpers.simple_record_as_golden(r, det.barcodes) for r in recs] == entry["results"]
+    assert sum(1 for r in entry["results"] if r["barcode_name"]) > len(reads) // 2
