@@ -108,35 +108,71 @@ def is_fastq(filename):
     raise ValueError("Invalid input file. File must start with '@' or '>'. Current file starts with: " + c)
 
 
-def _fastq_records(handle):
-    """4-line FASTQ records -> (title, seq, qual).  (The reference delegates to Biopython's
-    FastqGeneralIterator, which also accepts wrapped records; ONT FASTQ is 4-line.)"""
-    lines = iter(handle)
-    for head, seq, plus, qual in itertools.zip_longest(lines, lines, lines, lines):   # four lines per step
-        if qual is None:
-            if head.strip() == "" and seq is None:
-                return                                      # trailing blank line
-            raise ValueError("Malformed FASTQ record: " + head.strip())
-        if head[0] != "@":
+def _fastq_records_general(lines):
+    """(title, seq, qual) the way Biopython's ``FastqGeneralIterator`` (the reference's parser,
+    ``qcat/cli.py:260``) reads them: blank lines before a record are skipped, the title is stripped of
+    trailing whitespace, sequence and quality may be wrapped over several lines (quality lines are
+    collected until they are as long as the sequence, so a quality line may start with '@')."""
+    line = next(lines, "")
+    while line:
+        if line.strip() == "":                                  # blank line between / after records
+            line = next(lines, "")
+            continue
+        if line[0] != "@":
             raise ValueError("Records in Fastq files should start with '@' character")
-        seq = seq.rstrip("\n")
-        qual = qual.rstrip("\n")
-        if plus[0] != "+" or len(qual) != len(seq):
-            raise ValueError("Malformed FASTQ record: " + head.strip())
-        yield head[1:].rstrip("\n"), seq, qual
+        title = line[1:].rstrip()
+        seq_parts = []
+        line = next(lines, "")
+        while line and line[0] != "+":
+            seq_parts.append(line.rstrip())
+            line = next(lines, "")
+        if not line:
+            raise ValueError("End of file without quality information.")
+        second = line[1:].rstrip()
+        if second and second != title:
+            raise ValueError("Sequence and quality captions differ.")
+        seq = "".join(seq_parts)
+        if " " in seq:
+            raise ValueError("Whitespace is not allowed in the sequence.")
+        qual = next(lines, "").rstrip()
+        line = next(lines, "")
+        while line and len(qual) < len(seq):                   # wrapped quality
+            qual += line.rstrip()
+            line = next(lines, "")
+        if len(qual) != len(seq):
+            raise ValueError("Lengths of sequence and quality values differs for %s (%i and %i)." % (title, len(seq), len(qual)))
+        yield title, seq, qual
+
+
+def _fastq_records(handle):
+    """FASTQ records -> (title, seq, qual).  Fast path: four lines per step (ONT FASTQ); the first record
+    that is not a plain four-line record hands the rest of the file to the general parser above."""
+    lines = iter(handle)
+    for head, seq, plus, qual in itertools.zip_longest(lines, lines, lines, lines, fillvalue=""):
+        seq_s, qual_s = seq.rstrip(), qual.rstrip()
+        if head[:1] == "@" and plus[:1] == "+" and len(qual_s) == len(seq_s) and seq_s and " " not in seq_s \
+                and (len(plus) <= 2 or plus[1:].rstrip() in ("", head[1:].rstrip())):
+            yield head[1:].rstrip(), seq_s, qual_s
+            continue
+        for rec in _fastq_records_general(itertools.chain([head, seq, plus, qual], lines)):
+            yield rec
+        return
 
 
 def _fasta_records(handle):
+    """(title, seq) like Biopython's ``SimpleFastaParser`` (``qcat/cli.py:287``): text before the first '>'
+    is ignored, titles and sequence lines lose trailing whitespace, blanks and carriage returns inside
+    the sequence are dropped."""
     title, chunks = None, []
     for line in handle:
         if line.startswith(">"):
             if title is not None:
-                yield title, "".join(chunks)
-            title, chunks = line[1:].rstrip("\n"), []
+                yield title, "".join(chunks).replace(" ", "").replace("\r", "")
+            title, chunks = line[1:].rstrip(), []
         elif title is not None:
-            chunks.append(line.strip())
+            chunks.append(line.rstrip())
     if title is not None:
-        yield title, "".join(chunks)
+        yield title, "".join(chunks).replace(" ", "").replace("\r", "")
 
 
 def iter_fastx(reads_fx, fastq, batchsize):
@@ -145,15 +181,20 @@ def iter_fastx(reads_fx, fastq, batchsize):
     handle = open(reads_fx) if reads_fx else sys.stdin
     try:
         records = _fastq_records(handle) if fastq else ((t, s, None) for t, s in _fasta_records(handle))
-        for title, seq, qual in records:
-            name, comment = split_header(title)
-            names.append(name)
-            comments.append(comment)
-            seqs.append(seq)
-            quals.append(qual)
-            if len(names) >= batchsize:
-                yield names, comments, seqs, quals
-                names, comments, seqs, quals = [], [], [], []
+        try:
+            for title, seq, qual in records:
+                name, comment = split_header(title)
+                names.append(name)
+                comments.append(comment)
+                seqs.append(seq)
+                quals.append(qual)
+                if len(names) >= batchsize:
+                    yield names, comments, seqs, quals
+                    names, comments, seqs, quals = [], [], [], []
+        except ValueError as e:
+            # a malformed record: the reference logs the parser's message and leaves with status 1 (qcat/cli.py:275-277)
+            logging.error(str(e))
+            sys.exit(1)
     finally:
         if reads_fx:
             handle.close()

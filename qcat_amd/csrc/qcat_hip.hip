@@ -191,6 +191,8 @@ extern "C" int qcat_kit_describe(const qcat_kit* k, qcat_kit_info* out) {
     return 0;
 }
 
+static void kit_device_release(KitOnDevice& kd);
+
 extern "C" void qcat_kit_destroy(qcat_kit* k) {
     if (!k) return;
     int cur = 0;
@@ -199,9 +201,7 @@ extern "C" void qcat_kit_destroy(qcat_kit* k) {
         KitOnDevice& kd = k->dev[d];
         if (!kd.ready) continue;
         (void)hipSetDevice(d);
-        (void)hipFree(kd.kit); (void)hipFree(kd.codes); (void)hipFree(kd.ids);
-        (void)hipFree(kd.tables); (void)hipFree(kd.ascii);
-        if (kd.jit_module) (void)hipModuleUnload(kd.jit_module);
+        kit_device_release(kd);
     }
     (void)hipSetDevice(cur);
     delete k;
@@ -209,38 +209,50 @@ extern "C" void qcat_kit_destroy(qcat_kit* k) {
 
 extern "C" int qcat_kit_count_buckets(const qcat_kit* k) { return k ? k->hk.dk.n_buckets : QCAT_ERR_ARG; }
 
+static void kit_device_release(KitOnDevice& kd) {
+    (void)hipFree(kd.kit); (void)hipFree(kd.codes); (void)hipFree(kd.ids); (void)hipFree(kd.tables); (void)hipFree(kd.ascii);
+    if (kd.jit_module) (void)hipModuleUnload(kd.jit_module);
+    kd = KitOnDevice();
+}
+
+static int kit_upload(qcat_kit* k, KitOnDevice& kd) {
+    const HostKit& h = k->hk;
+    HIPCHK(hipMalloc((void**)&kd.kit, sizeof(DevKit)));
+    HIPCHK(hipMalloc((void**)&kd.codes, h.codes.size()));
+    HIPCHK(hipMalloc((void**)&kd.ids, h.ids.size() * 4));
+    HIPCHK(hipMalloc((void**)&kd.tables, h.tables.size() * 4));
+    HIPCHK(hipMalloc((void**)&kd.ascii, std::max<size_t>(1, h.ascii.size())));
+    HIPCHK(hipMemcpy(kd.kit, &h.dk, sizeof(DevKit), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(kd.codes, h.codes.data(), h.codes.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(kd.ids, h.ids.data(), h.ids.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(kd.tables, h.tables.data(), h.tables.size() * 4, hipMemcpyHostToDevice));
+    if (!h.ascii.empty()) HIPCHK(hipMemcpy(kd.ascii, h.ascii.data(), h.ascii.size(), hipMemcpyHostToDevice));
+    if (!k->jit_code.empty()) {
+        HIPCHK(hipModuleLoadData(&kd.jit_module, k->jit_code.data()));
+        char name[32];
+        for (int t = 0; t < h.dk.nt; ++t) {
+            if (k->jit_tpl[t]) {
+                snprintf(name, sizeof name, "qj_ad_%d", t);
+                HIPCHK(hipModuleGetFunction(&kd.jit_ad[t], kd.jit_module, name));
+                snprintf(name, sizeof name, "qj_am_%d", t);
+                HIPCHK(hipModuleGetFunction(&kd.jit_am[t], kd.jit_module, name));
+            }
+            for (int s2 = 0; s2 < 2; ++s2) if (k->jit_grp[t * 2 + s2]) {
+                snprintf(name, sizeof name, "qj_bc_%d", t * 2 + s2);
+                HIPCHK(hipModuleGetFunction(&kd.jit_bc[t * 2 + s2], kd.jit_module, name));
+            }
+        }
+    }
+    return 0;
+}
+
 static int kit_on_device(qcat_kit* k, int device, KitOnDevice** out) {
     if (device < 0 || device >= MAX_DEVICES) return set_err(QCAT_ERR_ARG, "device index out of range");
     std::lock_guard<std::mutex> lock(k->mu);
     KitOnDevice& kd = k->dev[device];
     if (!kd.ready) {
-        const HostKit& h = k->hk;
-        HIPCHK(hipMalloc((void**)&kd.kit, sizeof(DevKit)));
-        HIPCHK(hipMalloc((void**)&kd.codes, h.codes.size()));
-        HIPCHK(hipMalloc((void**)&kd.ids, h.ids.size() * 4));
-        HIPCHK(hipMalloc((void**)&kd.tables, h.tables.size() * 4));
-        HIPCHK(hipMalloc((void**)&kd.ascii, std::max<size_t>(1, h.ascii.size())));
-        HIPCHK(hipMemcpy(kd.kit, &h.dk, sizeof(DevKit), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(kd.codes, h.codes.data(), h.codes.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(kd.ids, h.ids.data(), h.ids.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(kd.tables, h.tables.data(), h.tables.size() * 4, hipMemcpyHostToDevice));
-        if (!h.ascii.empty()) HIPCHK(hipMemcpy(kd.ascii, h.ascii.data(), h.ascii.size(), hipMemcpyHostToDevice));
-        if (!k->jit_code.empty()) {
-            HIPCHK(hipModuleLoadData(&kd.jit_module, k->jit_code.data()));
-            char name[32];
-            for (int t = 0; t < h.dk.nt; ++t) {
-                if (k->jit_tpl[t]) {
-                    snprintf(name, sizeof name, "qj_ad_%d", t);
-                    HIPCHK(hipModuleGetFunction(&kd.jit_ad[t], kd.jit_module, name));
-                    snprintf(name, sizeof name, "qj_am_%d", t);
-                    HIPCHK(hipModuleGetFunction(&kd.jit_am[t], kd.jit_module, name));
-                }
-                for (int s2 = 0; s2 < 2; ++s2) if (k->jit_grp[t * 2 + s2]) {
-                    snprintf(name, sizeof name, "qj_bc_%d", t * 2 + s2);
-                    HIPCHK(hipModuleGetFunction(&kd.jit_bc[t * 2 + s2], kd.jit_module, name));
-                }
-            }
-        }
+        const int rc = kit_upload(k, kd);
+        if (rc) { kit_device_release(kd); return rc; }     // a failed upload leaves nothing behind: a retry starts clean
         kd.ready = true;
     }
     *out = &kd;
@@ -260,6 +272,17 @@ struct qcat_batch {
                                    // up to 19 bytes before / after a read's window
     uint64_t* offsets = nullptr;   // n_reads + 1
     uint32_t* true_len = nullptr;  // window-only batches (batch_upload_windows): the reads' real lengths
+};
+
+extern "C" void qcat_batch_destroy(qcat_batch* b);
+// owns a batch under construction: destroyed on every early return, handed over with release()
+struct BatchGuard {
+    qcat_batch* b;
+    explicit BatchGuard(qcat_batch* p) : b(p) {}
+    ~BatchGuard() { if (b) qcat_batch_destroy(b); }
+    qcat_batch* release() { qcat_batch* t = b; b = nullptr; return t; }
+    BatchGuard(const BatchGuard&) = delete;
+    BatchGuard& operator=(const BatchGuard&) = delete;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -623,15 +646,16 @@ extern "C" int qcat_batch_upload(qcat_ctx* c, const uint8_t* bases, const uint64
         if (offsets[r + 1] < offsets[r]) return set_err(QCAT_ERR_ARG, "offsets must be non-decreasing");
     HIPCHK(hipSetDevice(c->device));
     qcat_batch* b = new qcat_batch();
+    BatchGuard guard(b);
     b->device = c->device; b->n_reads = n_reads; b->n_bases = offsets[n_reads];
     hipError_t e1 = hipMalloc((void**)&b->bases_alloc, b->n_bases + 2 * BATCH_SLACK);
     if (e1 == hipSuccess) b->bases = b->bases_alloc + BATCH_SLACK;
     hipError_t e2 = hipMalloc((void**)&b->offsets, ((size_t)n_reads + 1) * 8);
-    if (e1 != hipSuccess || e2 != hipSuccess) { qcat_batch_destroy(b); return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch"); }
+    if (e1 != hipSuccess || e2 != hipSuccess) return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch");
     if (b->n_bases) HIPCHK(hipMemcpyAsync(b->bases, bases, b->n_bases, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b->offsets, offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    *out = b;
+    *out = guard.release();
     return 0;
 }
 
@@ -702,17 +726,18 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
         for (auto& th : pool) th.join();
     }
     qcat_batch* b = new qcat_batch();
+    BatchGuard guard(b);
     b->device = c->device; b->n_reads = n_reads; b->n_bases = total;
     hipError_t e1 = hipMalloc((void**)&b->bases_alloc, total + 2 * BATCH_SLACK);
     if (e1 == hipSuccess) b->bases = b->bases_alloc + BATCH_SLACK;
     hipError_t e2 = hipMalloc((void**)&b->offsets, ((size_t)n_reads + 1) * 8);
     hipError_t e3 = hipMalloc((void**)&b->true_len, ((size_t)n_reads + 1) * 4);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { qcat_batch_destroy(b); return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch"); }
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch");
     if (total) HIPCHK(hipMemcpyAsync(b->bases, c->pin_bases, total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b->offsets, c->pin_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b->true_len, c->pin_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));           // the pinned staging is reused by the next call
-    *out = b;
+    *out = guard.release();
     return 0;
 }
 
@@ -809,18 +834,19 @@ extern "C" int qcat_batch_synthesize(qcat_ctx* c, const qcat_kit* ckit, const qc
     HIPCHK(hipStreamSynchronize(c->stream));
     for (uint32_t i = 0; i < n; ++i) offs[i + 1] = offs[i] + lens[i];
     qcat_batch* b = new qcat_batch();
+    BatchGuard guard(b);
     b->device = c->device; b->n_reads = n; b->n_bases = offs[n];
     hipError_t e1 = hipMalloc((void**)&b->bases_alloc, b->n_bases + 2 * BATCH_SLACK);
     if (e1 == hipSuccess) b->bases = b->bases_alloc + BATCH_SLACK;
     hipError_t e2 = hipMalloc((void**)&b->offsets, ((size_t)n + 1) * 8);
-    if (e1 != hipSuccess || e2 != hipSuccess) { qcat_batch_destroy(b); return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for synthetic batch"); }
+    if (e1 != hipSuccess || e2 != hipSuccess) return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for synthetic batch");
     HIPCHK(hipMemcpyAsync(b->offsets, offs.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     if (n) hipLaunchKernelGGL(k_synth_write, dim3(blocks), dim3(256), 0, c->stream, s.p, s.t5, s.t3,
                               (int)s.has5, (int)s.has3, (uint64_t)0, n, b->offsets, b->bases);
     hipError_t es = hipStreamSynchronize(c->stream);
     if (es == hipSuccess) es = hipGetLastError();
-    if (es != hipSuccess) { qcat_batch_destroy(b); return set_err(QCAT_ERR_DEVICE, std::string("qcat_batch_synthesize: ") + hipGetErrorString(es)); }
-    *out = b;
+    if (es != hipSuccess) return set_err(QCAT_ERR_DEVICE, std::string("qcat_batch_synthesize: ") + hipGetErrorString(es));
+    *out = guard.release();
     return 0;
 }
 

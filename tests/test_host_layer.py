@@ -149,3 +149,28 @@ def test_kit_folder_yaml_loader(tmp_path):
     assert [l.kit for l in lays] == ["MYKIT"]                       # inactive entries are skipped
     assert lays[0].trim_offset == 3 and lays[0].barcode_set_2 is None and not lays[0].is_double_barcode()
     assert scanner.factory(kit_folder=str(tmp_path)).layouts[0].kit == "MYKIT"        # auto_detect honoured
+
+
+def test_fastx_parsers_follow_biopython(tmp_path):
+    """the reference reads FASTQ with Bio's FastqGeneralIterator and FASTA with SimpleFastaParser
+    (qcat/cli.py:260,287): wrapped records, stripped titles, blanks inside FASTA sequences, and
+    status 1 on a malformed record."""
+    import io
+    from qcat_amd import cli
+    plain = "@r1 some comment  \nACGT\n+\nIIII\n@r2\nGG\n+r2\n@I\n\n"
+    assert list(cli._fastq_records(io.StringIO(plain))) == [("r1 some comment", "ACGT", "IIII"), ("r2", "GG", "@I")]
+    wrapped = "\n@w1 c\t\nACGT\nAC\n+\nIII\n@II\n@w2\nTT\n+\nII\n"
+    assert list(cli._fastq_records(io.StringIO(wrapped))) == [("w1 c", "ACGTAC", "III@II"), ("w2", "TT", "II")]
+    mixed = "@a\nAC\n+\nII\n@b\nACG\nT\n+\nIIII\n@c\nA\n+\nI\n"                    # the fast path hands over mid-file
+    assert [r[0] for r in cli._fastq_records(io.StringIO(mixed))] == ["a", "b", "c"]
+    for bad, msg in (("@x\nACGT\n+\nII\n", "Lengths of sequence and quality"), ("x\nACGT\n+\nIIII\n", "should start with '@'"),
+                     ("@x\nAC GT\n+\nIIIII\n", "Whitespace"), ("@x\nACGT\n+y\nIIII\n", "captions differ"), ("@x\nACGT\n", "without quality")):
+        with pytest.raises(ValueError, match=msg):
+            list(cli._fastq_records(io.StringIO(bad)))
+    fasta = "junk before\n>t1 desc  \nAC GT\r\nTT\n>t2\n\n>t3\nA\n"
+    assert list(cli._fasta_records(io.StringIO(fasta))) == [("t1 desc", "ACGTTT"), ("t2", ""), ("t3", "A")]
+    bad = tmp_path / "bad.fastq"
+    bad.write_text("@ok\nAC\n+\nII\n@broken\nACGT\n+\nII\n")
+    with pytest.raises(SystemExit) as exc:
+        list(cli.iter_fastx(str(bad), True, 10))
+    assert exc.value.code == 1
