@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fold the FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh into profiles/<round>_traffic.json:
-usage: tools/update_traffic.py <round-tag> <workload>=<gpurun_out/prof_dir> ..."""
+usage: tools/update_traffic.py <round-tag> <workload>=<gpurun_out/prof_dir>[:reads per launch, default 1000000] ..."""
 import csv, json, os, sys
 from collections import defaultdict
 
@@ -12,6 +12,10 @@ out = {"_comment": "HBM traffic of the dominant kernel per launch, from rocprofv
        "(MI355X_MICROARCH.md, HBM section); all instantiations of the barcode DP kernel that ran in the step (static-letter kernels of every group, table kernels of every width class) are summed." % tag}
 for arg in sys.argv[2:]:
     wl, d = arg.split("=")
+    reads = 1000000
+    if ":" in d:
+        d, r = d.rsplit(":", 1)
+        reads = int(r)
     tot = defaultdict(float)
     for name, fn in (("FETCH_SIZE", "pmc3.csv"), ("WRITE_SIZE", "pmc4.csv")):
         per = defaultdict(list)
@@ -20,7 +24,6 @@ for arg in sys.argv[2:]:
                 if ("k_barcode_packed" in row["Kernel_Name"] or "k_barcode_static" in row["Kernel_Name"]) and row["Counter_Name"] == name:
                     per[row["Kernel_Name"]].append(float(row["Counter_Value"]))
         tot[name] = sum(sum(v) / len(v) for v in per.values())
-    reads = 1000000
     out[wl] = {"kernel": "k_barcode_static+k_barcode_packed", "reads_per_launch": reads, "fetch_size_kib": round(tot["FETCH_SIZE"], 1),
                "write_size_kib": round(tot["WRITE_SIZE"], 1), "bytes": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024)}
 with open(os.path.join(ROOT, "profiles", tag + "_traffic.json"), "w") as fh:
