@@ -345,6 +345,49 @@ def test_skipped_bucket_on_the_device(mode, kit, min_len, trim, middle):
     assert np.array_equal(cnt2, oracle_lib.scan(d, reads[:3000], counts=True, threads=8)[1])
 
 
+@pytest.mark.parametrize("mode,kit", [("epi2me", "PBC096"), ("epi2me", "NBD103/NBD104"), ("dual", None), ("epi2me", None)])
+def test_zero_scores_take_the_sequential_argmax(mode, kit, monkeypatch):
+    """The barcode kernels of the shipped kits keep one (max, first index) key per work unit instead of every
+    raw score; that is the reference's arg-max (scanner_base.py:125-134) unless the LARGEST raw score is exactly
+    0, where its `max_score == 0.0` clause makes the outcome depend on the list order -- those alignments are
+    redone sequentially (k_barcode_redo).  Windows that score exactly 0 against every target (letters outside
+    the alphabet score 0 with everything), against some targets, and mixtures, must equal the oracle and the
+    raw-score path (QCAT_HIP_RAWS=1)."""
+    det = scanner.factory(mode=mode, kit=kit)
+    base = synth.synth_batch(600, 1717, det.layouts, len(det.layouts) - 1, 0, error_rate=0.08)
+    reads = []
+    for i, r in enumerate(base):
+        k = i % 6
+        if k == 0:
+            reads.append("R" * (5 + i % 300))                       # every score 0: the LAST barcode wins (R2)
+        elif k == 1:
+            reads.append(r[:150].replace("A", "R").replace("C", "Y") + r[150:])
+        elif k == 2:
+            reads.append("N" * (1 + i % 40) + "RY" * (i % 90))
+        elif k == 3:
+            reads.append(r[:20 + i % 30])                           # tiny regions: scores around 0
+        elif k == 4:
+            reads.append(("ACGT"[i % 4]) * (3 + i % 200))
+        else:
+            reads.append(r)
+    d = det.descriptor()
+    want, want_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
+    bases, offsets = native.pack_reads(reads)
+    monkeypatch.setenv("QCAT_HIP_SUMMARY", "1")                     # key path also for the small sets
+    for raws in (None, "1"):
+        if raws:
+            monkeypatch.setenv("QCAT_HIP_RAWS", raws)
+        cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+        got = native.NativeContext(0).scan(native.NativeKit(d), bases, offsets, counts=cnt)
+        assert got.tobytes() == want.tobytes(), raws
+        assert np.array_equal(cnt, want_cnt)
+    # the all-zero windows really exercise the clause: the last barcode of the set is called with score 0
+    if mode == "epi2me" and kit:
+        _, tr = oracle_lib.scan(d, reads[:1], trace=True)
+        nb = len(det.layouts[int(tr[0]["used_tpl"])].barcode_set_1)
+        assert int(tr[0]["bc_idx"][0]) == nb - 1 and int(tr[0]["bc_raw"][0]) == 0
+
+
 def test_timing_ring_and_stream_accessor():
     """qcat_ctx_last_timing averages over the scans since the previous call (no sync between scans);
     qcat_ctx_stream hands out the context's stream for stream-ordered RCCL calls."""
