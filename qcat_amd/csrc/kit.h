@@ -51,8 +51,16 @@ struct DevSet {
     int32_t min_raw_middle;     // smallest raw with raw*100.0/tlen >= middle_min_score (--detect-middle)
     int32_t static_kernel;      // generated static-letter kernel of this group (kernels_static.inc), -1: none
     int32_t case_off;           // ids blob: n_pairs entries (pair case, barcode of half 0 or -1, barcode of half 1 or -1)
-    int32_t n_pairs;            // target pairs the static kernel runs for this group
+    int32_t n_pairs;            // target pairs the static kernel runs for this group (quad mode: the pairs outside every quad)
+    int32_t quad_off;           // ids blob: n_quads entries (quad case, barcode a, b, c, d) -- two pairs in one row pass
+    int32_t n_quads;
 };
+
+// work units of a static-letter barcode group per tile: chunks of quads first, then chunks of the pairs left over
+inline int static_units(int n_quads, int n_pairs, int chunk_b) {
+    const int cq = chunk_b / 4 > 0 ? chunk_b / 4 : 1, cp = chunk_b / 2 > 0 ? chunk_b / 2 : 1;
+    return (n_quads + cq - 1) / cq + (n_pairs + cp - 1) / cp;
+}
 
 struct DevTpl {
     int32_t len, trim_offset, is_double, den, kit_slot;

@@ -164,7 +164,7 @@ extern "C" int qcat_kit_attach_code(qcat_kit* k, const void* code, uint64_t size
             const int np = pair_offsets[t * 2 + s + 1] - pair_offsets[t * 2 + s];
             if (np <= 0) continue;
             q.static_kernel = QCAT_JIT_BASE + t * 2 + s;
-            q.n_pairs = np;
+            q.n_pairs = np; q.n_quads = 0; q.quad_off = 0;
             q.case_off = (int32_t)h.ids.size();          // (pair case, barcode of half 0, barcode of half 1) per pair
             h.ids.insert(h.ids.end(), ent, ent + (size_t)np * 3);
             k->jit_grp[t * 2 + s] = true;

@@ -187,7 +187,9 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
                                  % (name, m - up_ + 1, _chain(tg[up_:])))
                 parts.append("};\n")
                 entries[g].append((pr, ba, bb))
-            parts.append("struct QSGJ_%d {\n    static constexpr int M = %d;\n"
+            parts.append("struct QSGJ_%d {\n    static constexpr int M = %d;\n    static constexpr int HAS_QUADS = 0;\n"
+                         "    static __device__ __forceinline__ void run4(int, const uint8_t*, int, int, h2, u32, const u32 (&)[4], h2, h2, "
+                         "u32&, u32&, u32&, u32&) {}\n"
                          "    static __device__ __forceinline__ void run(int pair, const uint8_t* qbuf, int lane, int Lmax, h2 gL2, "
                          "u32 special, const u32 (&ltr)[4], h2 rowoff, h2 coloff, u32& ra, u32& rb) {\n        ra = 0; rb = 0;\n"
                          "        switch (pair) {\n" % (g, m))

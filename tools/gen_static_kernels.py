@@ -21,6 +21,7 @@ from qcat_amd import config as qconfig          # noqa: E402
 from qcat_amd import scanner                    # noqa: E402
 
 OUT = os.path.join(ROOT, "qcat_amd", "csrc", "static_generated.inc")
+QUAD_MIN_TARGETS = 48       # families this large also get four-target chains (the big sets dominate the run time)
 CODE = {"A": 0, "T": 1, "G": 2, "C": 3}
 ACODE = {"A": 0, "T": 1, "G": 2, "C": 3, "N": 4}        # adapter templates also hold barcode placeholders
 
@@ -125,6 +126,7 @@ def render():
     """text of static_generated.inc plus (n kernels, n targets, n templates)"""
     fams, templates, fused, members = collect()
     reg = []
+    quad_reg = []                                    # (kernel, quad case, pair a, pair b)
     fh = _Buf()
     if True:
         fh.write("// GENERATED by tools/gen_static_kernels.py -- do not edit.\n")
@@ -139,8 +141,13 @@ def render():
             for t in targets:
                 groups.setdefault(frozenset(members[t]), []).append(t)
             pairs = []
+            quads = []                                   # (pair index a, pair index b): consecutive pairs of one membership group
             for grp in groups.values():
+                first = len(pairs)
                 pairs.extend(pair_up(grp, u))
+                if len(targets) >= QUAD_MIN_TARGETS:
+                    quads.extend((i, i + 1) for i in range(first, len(pairs) - 1, 2)
+                                 if pairs[i][0] != pairs[i][1] and pairs[i + 1][0] != pairs[i + 1][1])
             npairs = len(pairs)
             for pr, (ta, tb, up_) in enumerate(pairs):
                 reg.append((fnv1a64([CODE[c] for c in ta]), kid, 2 * pr, ta))
@@ -153,7 +160,31 @@ def render():
                     fh.write("    static __device__ __forceinline__ void %s(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
                              % (name, m - up_ + 1, chain(t[up_:], CODE)))
                 fh.write("};\n")
-            fh.write("struct QSG_%d {\n    static constexpr int M = %d;\n" % (kid, m))
+            # quads: two pairs in ONE row pass -- the columns all four targets share (at least the flank) and the
+            # per-row work (selector, score registers, boundary) are paid once per four targets (static_barcode_rows4)
+            for q, (pa, pb) in enumerate(quads):
+                (a1, a2, ua), (b1, b2, ub) = pairs[pa], pairs[pb]
+                u0 = min(len(os.path.commonprefix([a1, a2, b1, b2])), ua, ub)
+                quad_reg.append((kid, q, pa, pb))
+                fh.write("struct QSQ_%d_%d {      // %d columns shared by all four, +%d / +%d inside the pairs\n" % (kid, q, u0, ua - u0, ub - u0))
+                fh.write("    static __device__ __forceinline__ void pre0(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
+                         % (u0 + 1, chain(a1[:u0], CODE) if u0 else ""))
+                for name, t, lo, hi in (("prea", a1, u0, ua), ("ta", a1, ua, m), ("tb", a2, ua, m),
+                                        ("preb", b1, u0, ub), ("tc", b1, ub, m), ("td", b2, ub, m)):
+                    fh.write("    static __device__ __forceinline__ void %s(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
+                             % (name, hi - lo + 1, chain(t[lo:hi], CODE) if hi > lo else ""))
+                fh.write("};\n")
+            nq = len(quads)
+            fh.write("struct QSG_%d {\n    static constexpr int M = %d;\n    static constexpr int HAS_QUADS = %d;\n" % (kid, m, 1 if nq else 0))
+            fh.write("    static __device__ __forceinline__ void run4(int quad, const uint8_t* qbuf, int lane, int Lmax, h2 gL2, "
+                     "u32 special, const u32 (&ltr)[4], h2 rowoff, h2 coloff, u32& ra, u32& rb, u32& rc, u32& rd) {\n"
+                     "        ra = 0; rb = 0; rc = 0; rd = 0;\n        switch (quad) {\n")
+            for q, (pa, pb) in enumerate(quads):
+                (a1, a2, ua), (b1, b2, ub) = pairs[pa], pairs[pb]
+                u0 = min(len(os.path.commonprefix([a1, a2, b1, b2])), ua, ub)
+                fh.write("        case %d: static_barcode_rows4<M, %d, %d, %d, QSQ_%d_%d>(qbuf, lane, Lmax, gL2, special, ltr, rowoff, coloff, ra, rb, rc, rd); break;\n"
+                         % (q, u0, ua - u0, ub - u0, kid, q))
+            fh.write("        default: break;\n        }\n    }\n")
             fh.write("    static __device__ __forceinline__ void run(int pair, const uint8_t* qbuf, int lane, int Lmax, h2 gL2, "
                      "u32 special, const u32 (&ltr)[4], h2 rowoff, h2 coloff, u32& ra, u32& rb) {\n        ra = 0; rb = 0;\n        switch (pair) {\n")
             for pr, (ta, tb, up_) in enumerate(pairs):
@@ -168,7 +199,13 @@ def render():
         for h, kid, case, seq in reg:
             fh.write("    {0x%016XULL, %d, %d, \"%s\"},\n" % (h, kid, case, seq))
         fh.write("};\nstatic const int g_n_static_targets = %d;\n" % len(reg))
-        fh.write("static const int g_static_kernel_M[] = {%s};\n\n" % ", ".join(str(m) for (_, _, m) in fams))
+        fh.write("static const int g_static_kernel_M[] = {%s};\n" % ", ".join(str(m) for (_, _, m) in fams))
+        fh.write("// quads of a kernel: (kernel, quad case, pair case a, pair case b); a kit group runs them when it scans both pairs\n")
+        fh.write("struct StaticQuad { int16_t kernel, quad, pair_a, pair_b; };\n")
+        fh.write("static const StaticQuad g_static_quads[] = {\n")
+        for kid, q, pa, pb in quad_reg:
+            fh.write("    {%d, %d, %d, %d},\n" % (kid, q, pa, pb))
+        fh.write("    {-1, -1, -1, -1}\n};\nstatic const int g_n_static_quads = %d;\n\n" % len(quad_reg))
         fh.write("static inline void launch_barcode_static(int kernel, dim3 grid, hipStream_t stream, const StaticArgs& a) {\n"
                  "    if (kernel >= QCAT_JIT_BASE) { jit_launch(QCAT_JIT_BARCODE, kernel - QCAT_JIT_BASE, grid, stream, &a); return; }\n"
                  "    switch (kernel) {\n")
