@@ -211,6 +211,14 @@ int  qcat_kit_attach_code(qcat_kit* kit, const void* code, uint64_t size,
                           const int32_t* template_flags, const int32_t* group_flags,
                           const int32_t* pair_offsets, const int32_t* pair_entries);
 
+/* The same with four-target chains: group g may also export cases of qj_bc_<g>'s run4 switch; quad_entries holds, at
+ * [quad_offsets[g], quad_offsets[g+1]), the 5-tuples (quad case, kit barcodes a, b, c, d -- all present).  Every barcode
+ * of a flagged group must appear exactly once over its pair and quad lists.  quad_offsets == NULL: no quads. */
+int  qcat_kit_attach_code_quads(qcat_kit* kit, const void* code, uint64_t size,
+                                const int32_t* template_flags, const int32_t* group_flags,
+                                const int32_t* pair_offsets, const int32_t* pair_entries,
+                                const int32_t* quad_offsets, const int32_t* quad_entries);
+
 int  qcat_ctx_create(int device, qcat_ctx** out);
 void qcat_ctx_destroy(qcat_ctx* ctx);
 

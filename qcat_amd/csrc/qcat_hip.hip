@@ -115,9 +115,22 @@ extern "C" int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {
     return 0;
 }
 
+extern "C" int qcat_kit_attach_code_quads(qcat_kit* k, const void* code, uint64_t size,
+                                          const int32_t* template_flags, const int32_t* group_flags,
+                                          const int32_t* pair_offsets, const int32_t* pair_entries,
+                                          const int32_t* quad_offsets, const int32_t* quad_entries);
+
 extern "C" int qcat_kit_attach_code(qcat_kit* k, const void* code, uint64_t size,
                                     const int32_t* template_flags, const int32_t* group_flags,
                                     const int32_t* pair_offsets, const int32_t* pair_entries) {
+    return qcat_kit_attach_code_quads(k, code, size, template_flags, group_flags, pair_offsets, pair_entries, nullptr, nullptr);
+}
+
+extern "C" int qcat_kit_attach_code_quads(qcat_kit* k, const void* code, uint64_t size,
+                                          const int32_t* template_flags, const int32_t* group_flags,
+                                          const int32_t* pair_offsets, const int32_t* pair_entries,
+                                          const int32_t* quad_offsets, const int32_t* quad_entries) {
+    if (quad_offsets && !quad_entries) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: quad offsets without quad entries");
     if (!k || !code || !size || !template_flags || !group_flags || !pair_offsets || !pair_entries)
         return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: null argument");
     std::lock_guard<std::mutex> lock(k->mu);
@@ -130,18 +143,30 @@ extern "C" int qcat_kit_attach_code(qcat_kit* k, const void* code, uint64_t size
     // validate the pair lists BEFORE anything is bound: the barcode kernel writes its raw scores at the
     // kit barcode indices named here, and k_barcode_select reads one score per barcode of the set
     for (int g = 0; g < 2 * MAX_T; ++g)
-        if (pair_offsets[g] < 0 || pair_offsets[g + 1] < pair_offsets[g])
-            return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: pair_offsets must be non-negative and non-decreasing");
+        if (pair_offsets[g] < 0 || pair_offsets[g + 1] < pair_offsets[g] ||
+            (quad_offsets && (quad_offsets[g] < 0 || quad_offsets[g + 1] < quad_offsets[g])))
+            return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: pair / quad offsets must be non-negative and non-decreasing");
     for (int t = 0; t < d.nt; ++t)
         for (int s = 0; s < nsets; ++s) {
             const DevSet& q = d.tpl[t].sets[s];
             if (!group_flags[t * 2 + s] || !d.barcode_f16 || q.static_kernel >= 0 || q.n <= 0) continue;
             const int32_t* ent = pair_entries + (size_t)pair_offsets[t * 2 + s] * 3;
             const int np = pair_offsets[t * 2 + s + 1] - pair_offsets[t * 2 + s];
-            if (np <= 0) continue;
-            if (np > q.n) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: more target pairs than barcodes in a set");
+            const int nqd = quad_offsets ? quad_offsets[t * 2 + s + 1] - quad_offsets[t * 2 + s] : 0;
+            if (np <= 0 && nqd <= 0) continue;
+            if (np > q.n || nqd > q.n) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: more target pairs than barcodes in a set");
             std::vector<char> seen((size_t)q.n, 0);
             int covered = 0;
+            for (int i = 0; i < nqd; ++i) {
+                const int32_t* qe = quad_entries + ((size_t)quad_offsets[t * 2 + s] + i) * 5;
+                if (qe[0] < 0) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: negative quad case");
+                for (int m2 = 1; m2 <= 4; ++m2) {
+                    const int32_t b = qe[m2];
+                    if (b < 0 || b >= q.n) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: barcode index outside its set");
+                    if (seen[(size_t)b]) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: a barcode appears in two target pairs");
+                    seen[(size_t)b] = 1; ++covered;
+                }
+            }
             for (int i = 0; i < np; ++i) {
                 if (ent[i * 3] < 0) return set_err(QCAT_ERR_ARG, "qcat_kit_attach_code: negative pair case");
                 for (int half = 1; half <= 2; ++half) {
@@ -162,11 +187,18 @@ extern "C" int qcat_kit_attach_code(qcat_kit* k, const void* code, uint64_t size
             if (!group_flags[t * 2 + s] || !d.barcode_f16 || q.static_kernel >= 0 || q.n <= 0) continue;
             const int32_t* ent = pair_entries + (size_t)pair_offsets[t * 2 + s] * 3;
             const int np = pair_offsets[t * 2 + s + 1] - pair_offsets[t * 2 + s];
-            if (np <= 0) continue;
+            const int nqd = quad_offsets ? quad_offsets[t * 2 + s + 1] - quad_offsets[t * 2 + s] : 0;
+            if (np <= 0 && nqd <= 0) continue;
             q.static_kernel = QCAT_JIT_BASE + t * 2 + s;
-            q.n_pairs = np; q.n_quads = 0; q.quad_off = 0;
+            q.n_pairs = np;
             q.case_off = (int32_t)h.ids.size();          // (pair case, barcode of half 0, barcode of half 1) per pair
             h.ids.insert(h.ids.end(), ent, ent + (size_t)np * 3);
+            q.n_quads = nqd;
+            q.quad_off = (int32_t)h.ids.size();          // (quad case, barcodes a, b, c, d) per quad
+            if (nqd > 0) {
+                const int32_t* qe = quad_entries + (size_t)quad_offsets[t * 2 + s] * 5;
+                h.ids.insert(h.ids.end(), qe, qe + (size_t)nqd * 5);
+            }
             k->jit_grp[t * 2 + s] = true;
         }
     }

@@ -33,6 +33,7 @@ from .codes import ASCII_TO_CODE
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 ARCH = "gfx950"
 MAX_TEMPLATES = 16
+QUAD_MIN_TARGETS = 48            # as tools/gen_static_kernels.py: sets this large also get four-target chains
 _LETTER = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4}          # code -> E[] index: A, T, G, C (+ N in templates)
 
 
@@ -154,6 +155,7 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
     parts = ['#include "jit_prelude.inc"\n', "namespace qk {\n"]
     entry = []
     entries = [[] for _ in range(2 * MAX_TEMPLATES)]          # per group: (pair case, barcode a, barcode b or -1)
+    quads = [[] for _ in range(2 * MAX_TEMPLATES)]            # per group: (quad case, barcodes a, b, c, d, shared column counts)
     for t, lay in enumerate(descriptor.layouts):
         tcodes = _codes(lay.sequence)
         if t not in skip_templates and all(c <= 4 for c in tcodes) and 1 <= len(tcodes) <= 128:
@@ -177,7 +179,30 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
                 continue
             u = len(up)
             pairs = _pair_up(targets, u)                     # [(barcode a, barcode b or -1, shared columns)]
-            for pr, (ba, bb, up_) in enumerate(pairs):
+            # big sets: two complete pairs per row pass (static_barcode_rows4) -- the flank columns and the per-row
+            # work once per four targets; the pairs left over keep their own chains
+            quad_list, left = [], []
+            if len(targets) >= QUAD_MIN_TARGETS:
+                full = [p for p in pairs if p[1] >= 0]
+                left = [p for p in pairs if p[1] < 0]
+                if len(full) % 2:
+                    left.insert(0, full.pop())
+                quad_list = [(full[i], full[i + 1]) for i in range(0, len(full), 2)]
+            else:
+                left = pairs
+            for qd, ((a1, a2, ua), (b1, b2, ub)) in enumerate(quad_list):
+                t1, t2, t3, t4 = targets[a1], targets[a2], targets[b1], targets[b2]
+                u0 = min(_lcp(t1, t3), ua, ub)
+                parts.append("struct QSQJ_%d_%d {\n" % (g, qd))
+                parts.append("    static __device__ __forceinline__ void pre0(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
+                             % (u0 + 1, _chain(t1[:u0]) if u0 else ""))
+                for name, tg, lo, hi in (("prea", t1, u0, ua), ("ta", t1, ua, m), ("tb", t2, ua, m),
+                                         ("preb", t3, u0, ub), ("tc", t3, ub, m), ("td", t4, ub, m)):
+                    parts.append("    static __device__ __forceinline__ void %s(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
+                                 % (name, hi - lo + 1, _chain(tg[lo:hi]) if hi > lo else ""))
+                parts.append("};\n")
+                quads[g].append((qd, a1, a2, b1, b2, u0, ua - u0, ub - u0))
+            for pr, (ba, bb, up_) in enumerate(left):
                 ta, tb = targets[ba], targets[bb if bb >= 0 else ba]
                 parts.append("struct QSPJ_%d_%d {\n" % (g, pr))
                 parts.append("    static __device__ __forceinline__ void pre(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[4]) { %s }\n"
@@ -187,21 +212,26 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
                                  % (name, m - up_ + 1, _chain(tg[up_:])))
                 parts.append("};\n")
                 entries[g].append((pr, ba, bb))
-            parts.append("struct QSGJ_%d {\n    static constexpr int M = %d;\n    static constexpr int HAS_QUADS = 0;\n"
-                         "    static __device__ __forceinline__ void run4(int, const uint8_t*, int, int, h2, u32, const u32 (&)[4], h2, h2, "
-                         "u32&, u32&, u32&, u32&) {}\n"
+            parts.append("struct QSGJ_%d {\n    static constexpr int M = %d;\n    static constexpr int HAS_QUADS = %d;\n"
+                         "    static __device__ __forceinline__ void run4(int quad, const uint8_t* qbuf, int lane, int Lmax, h2 gL2, "
+                         "u32 special, const u32 (&ltr)[4], h2 rowoff, h2 coloff, u32& ra, u32& rb, u32& rc, u32& rd) {\n"
+                         "        ra = 0; rb = 0; rc = 0; rd = 0;\n        switch (quad) {\n" % (g, m, 1 if quad_list else 0))
+            for qd, a1, a2, b1, b2, u0, da, db in quads[g]:
+                parts.append("        case %d: static_barcode_rows4<M, %d, %d, %d, QSQJ_%d_%d>(qbuf, lane, Lmax, gL2, special, ltr, rowoff, coloff, ra, rb, rc, rd); break;\n"
+                             % (qd, u0, da, db, g, qd))
+            parts.append("        default: break;\n        }\n    }\n"
                          "    static __device__ __forceinline__ void run(int pair, const uint8_t* qbuf, int lane, int Lmax, h2 gL2, "
                          "u32 special, const u32 (&ltr)[4], h2 rowoff, h2 coloff, u32& ra, u32& rb) {\n        ra = 0; rb = 0;\n"
-                         "        switch (pair) {\n" % (g, m))
-            for pr, (ba, bb, up_) in enumerate(pairs):
+                         "        switch (pair) {\n")
+            for pr, (ba, bb, up_) in enumerate(left):
                 parts.append("        case %d: static_barcode_rows2<M, %d, QSPJ_%d_%d>(qbuf, lane, Lmax, gL2, special, ltr, rowoff, coloff, ra, rb); break;\n"
                              % (pr, up_, g, pr))
             parts.append("        default: break;\n        }\n    }\n};\n")
-            entry.append('extern "C" __global__ void __launch_bounds__(qk::PK_WAVES * 64, 4) '
-                         "qj_bc_%d(qk::StaticArgs a) { qk::barcode_static_body<qk::QSGJ_%d>(a); }\n" % (g, g))
+            entry.append('extern "C" __global__ void __launch_bounds__(qk::PK_WAVES * 64, %d) '
+                         "qj_bc_%d(qk::StaticArgs a) { qk::barcode_static_body<qk::QSGJ_%d>(a); }\n" % (2 if quad_list else 4, g, g))
             grp_flags[g] = 1
     parts.append("}  // namespace qk\n")
-    return "".join(parts + entry), tpl_flags, grp_flags, entries
+    return "".join(parts + entry), tpl_flags, grp_flags, entries, [[q[:5] for q in g] for g in quads]
 
 
 def _prelude_digest():
@@ -318,7 +348,7 @@ def attach(native_kit, handle=None):
     info = native_kit.describe()
     if not needs_code(info):
         return info
-    source, tpl_flags, grp_flags, entries = generate(native_kit.descriptor)
+    source, tpl_flags, grp_flags, entries, quads = generate(native_kit.descriptor)
     if not any(tpl_flags) and not any(grp_flags):
         return info
     blob = compile_source(source)
@@ -332,8 +362,15 @@ def attach(native_kit, handle=None):
         offs.append(len(flat) // 3)
     po = (C.c_int32 * len(offs))(*offs)
     pe = (C.c_int32 * max(1, len(flat)))(*flat)
-    hip.check(hip.lib.qcat_kit_attach_code(handle if handle is not None else native_kit.handle,
-                                           blob, len(blob), tf, gf, po, pe))
+    qoffs, qflat = [0], []
+    for g in range(2 * MAX_TEMPLATES):
+        for q in quads[g]:
+            qflat.extend(q)
+        qoffs.append(len(qflat) // 5)
+    qo = (C.c_int32 * len(qoffs))(*qoffs)
+    qe = (C.c_int32 * max(1, len(qflat)))(*qflat)
+    hip.check(hip.lib.qcat_kit_attach_code_quads(handle if handle is not None else native_kit.handle,
+                                                 blob, len(blob), tf, gf, po, pe, qo, qe))
     return native_kit.describe(handle)
 
 

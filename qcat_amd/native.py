@@ -238,6 +238,8 @@ class HipLibrary(object):
             "qcat_kit_describe": (C.c_int, [vp, C.POINTER(KitInfo)]),
             "qcat_kit_attach_code": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.POINTER(i32), C.POINTER(i32),
                                               C.POINTER(i32), C.POINTER(i32)]),
+            "qcat_kit_attach_code_quads": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.POINTER(i32), C.POINTER(i32),
+                                                    C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
             "qcat_ctx_stream": (vp, [vp]),
             "qcat_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
             "qcat_ctx_destroy": (None, [vp]),
