@@ -363,8 +363,8 @@ def cpu_legs(a, out, lib, kit, sp, desc, det, cfg, mode, recs, avg, elapsed):
                     "(issue rates measured by tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt): static-letter kernels "
                     "v_pk_add_f16 + v_pk_maximum3_f16 = 8.38 cycles; table kernels 12.55 (fp16 lanes) / 15.2 (u16 lanes); "
                     "frac_of_valu_peak = ideal DP time of both phases / whole step time.  Cells are the "
-                    "reference-defined ones (SURVEY.md 8d); the barcode chains run two targets per row pass and "
-                    "compute their shared upstream-flank columns once, so `barcode.frac` can exceed 1")
+                    "reference-defined ones (SURVEY.md 8d); the barcode chains run two or four targets per row pass "
+                    "and compute the columns they share (at least the upstream flank) once, so `barcode.frac` can exceed 1")
     out["valu"] = valu
 
 
