@@ -54,6 +54,9 @@ struct DevSet {
     int32_t n_pairs;            // target pairs the static kernel runs for this group (quad mode: the pairs outside every quad)
     int32_t quad_off;           // ids blob: n_quads entries (quad case, barcode a, b, c, d) -- two pairs in one row pass
     int32_t n_quads;
+    int32_t bs_off;             // ids blob: per barcode the target letters as bit words (letter bit 1 lo, hi, letter bit 0 lo, hi)
+                                // for the bit-sliced kernels (kernels_bitslice.inc); -1: set not eligible
+    int32_t hot_len;            // the region length almost every job of this set has: barcode + 2 * extension + 1
 };
 
 // work units of a static-letter barcode group per tile: chunks of quads first, then chunks of the pairs left over
@@ -83,6 +86,7 @@ struct DevKit {
     int32_t min_read_length, trim_reads;   // the driver's min-length filter of the histogram (qcat/cli.py:521-534)
     int32_t fast_ok;            // every template/set is eligible for the packed fast path
     int32_t barcode_f16;        // barcode tables hold binary16 high bytes (fp16-lane barcode kernels)
+    int32_t bs_ok;              // the barcode scoring is +1 / -1 / gap 1 with N matching nothing: bit-sliced kernels allowed
     uint32_t special_adapter;   // v_perm pool bytes for query codes N, X, other, PAD (adapter)
     uint32_t special_barcode;   //   "    (barcode alignments)
     uint32_t letter_tbl_barcode[4];   // score dword of a column whose target letter is A, T, G, C (static kernels)

@@ -24,6 +24,7 @@
 #include "kernels_common.inc"
 #include "kernels_generic.inc"
 #include "kernels_packed.inc"
+#include "kernels_bitslice.inc"
 #include "packed_host.inc"
 #include "kernels_static.inc"
 #include "kernels_middle.inc"
@@ -329,6 +330,7 @@ struct qcat_ctx {
     size_t cap_win = 0, cap_wlen = 0, cap_recs = 0, cap_reads = 0, cap_buckets = 0;
     uint8_t* win = nullptr;
     int32_t* wlen = nullptr;
+    uint8_t* wspec = nullptr; size_t cap_wspec = 0;     // per read end: the window holds a letter outside A, C, G, T, N
     EndRec* recs = nullptr;
     qcat_result* results = nullptr;
     unsigned long long* counts = nullptr;
@@ -383,7 +385,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->recs); (void)hipFree(c->results);
+    (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->wspec); (void)hipFree(c->recs); (void)hipFree(c->results);
     (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows);
     packed_scratch_free(&c->packed);
     if (c->pin_bases) (void)hipHostFree(c->pin_bases);
@@ -472,6 +474,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     // adapter phase: one launch per template (tiles of other kits record "did not compete"), the
     // launches of a scan run concurrently
     PackedScratch* sc = &c->packed;
+    sc->wspec = nullptr;                                  // interiors: no letter flags, no bit-sliced classes
     if ((rc = packed_prepare(st, hk, (uint32_t)slots, sc))) return set_err(rc, packed_last_error());
     const uint32_t tiles = (uint32_t)(slots / PK_TILE);
     fork_join(sc, st, hk.nt, [&](int t, hipStream_t q) {
@@ -482,7 +485,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     {
         const uint32_t fblocks = (uint32_t)std::min<uint64_t>((slots + 255) / 256, 2048);
         hipLaunchKernelGGL(k_adapter_finish, dim3(fblocks), dim3(256), 0, st, kp.kit, c->mid_len, (uint32_t)slots,
-                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1);
+                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1, (const uint8_t*)nullptr);
     }
     const int nsets = hk.mode == QCAT_MODE_DUAL ? 2 : 1;
     rc = packed_barcode(st, kp, hk, (uint32_t)slots, c->mid_recs, sc, [&](uint32_t max_tiles) {
@@ -515,6 +518,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
 
     if ((rc = grow(&c->win, &c->cap_win, n_ends * WIN_STRIDE + 64))) return rc;     // + slack: k_job_gather reads whole dwords
     if ((rc = grow(&c->wlen, &c->cap_wlen, n_ends))) return rc;
+    if ((rc = grow(&c->wspec, &c->cap_wspec, n_ends))) return rc;
     if ((rc = grow(&c->recs, &c->cap_recs, n_ends))) return rc;
     if ((rc = grow(&c->results, &c->cap_reads, (size_t)n))) return rc;
     if ((rc = grow(&c->counts, &c->cap_buckets, (size_t)hk.n_buckets))) return rc;
@@ -542,14 +546,16 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     if (resume_kit_mask < 0) {
         uint64_t threads = (uint64_t)n_ends * (WIN_STRIDE / 16);
         uint32_t blocks = (uint32_t)((threads + 255) / 256);
+        HIPCHK(hipMemsetAsync(c->wspec, 0, n_ends, c->stream));
         hipLaunchKernelGGL(k_pack_windows, dim3(blocks), dim3(256), 0, c->stream,
-                           b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen);
+                           b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen, c->wspec);
         mark(c, "k_pack_windows");
     }
     const bool use_packed = hk.fast_ok && !c->force_generic && packed_supported(hk);
     if (hk.mode == QCAT_MODE_SIMPLE && adapter_only) return set_err(QCAT_ERR_ARG, "simple mode has no adapter templates to vote with");
     if (resume_kit_mask >= 0 && !(use_packed && c->packed.slices_single))
         return set_err(QCAT_ERR_UNSUPPORTED, "the adapter pass of this kit cannot be resumed per kit (table or general kernels)");
+    c->packed.wspec = c->wspec; c->packed.win = c->win;
     if (hk.mode == QCAT_MODE_SIMPLE) {
         uint32_t blocks = (uint32_t)((n_ends + GEN_THREADS - 1) / GEN_THREADS);
         hipLaunchKernelGGL(k_scan_simple, dim3(blocks), dim3(GEN_THREADS), 0, c->stream, kp, c->win, c->wlen, (uint32_t)n_ends, c->recs,

@@ -388,6 +388,49 @@ def test_zero_scores_take_the_sequential_argmax(mode, kit, monkeypatch):
         assert int(tr[0]["bc_idx"][0]) == nb - 1 and int(tr[0]["bc_raw"][0]) == 0
 
 
+@pytest.mark.parametrize("mode,kit,ends", [("epi2me", "PBC096", native.ENDS_BOTH), ("epi2me", "NBD103/NBD104", native.ENDS_5P),
+                                           ("dual", None, native.ENDS_BOTH), ("epi2me", None, native.ENDS_BOTH),
+                                           ("epi2me", "RBK004", native.ENDS_BOTH)])
+def test_bit_sliced_barcode_kernels_equal_the_binary16_kernels_and_the_oracle(mode, kit, ends, monkeypatch):
+    """Large batches send the full super-tiles of the two hot region lengths through the bit-sliced kernels
+    (kernels_bitslice.inc) and the rest through the packed-binary16 kernels; both must give the oracle's records.
+    The batch mixes plain reads (hot), reads with N (hot: N matches nothing), reads with letters outside the
+    alphabet (never hot), truncated reads (other lengths) and degenerate ones."""
+    det = scanner.factory(mode=mode, kit=kit)
+    t5 = len(det.layouts) - 1 if kit else (3 if mode == "epi2me" else 1)
+    t3 = 0 if len(det.layouts) > 1 else -1
+    if kit is None and mode == "epi2me":
+        t3 = 2
+    n = 30000
+    reads = synth.synth_batch(n, 9090, det.layouts, t5, t3, error_rate=0.08)
+    for i in range(0, n, 11):
+        r = reads[i]
+        k = (i // 11) % 5
+        if k == 0:
+            reads[i] = r[:40] + "N" + r[41:70] + "NN" + r[72:]
+        elif k == 1:
+            reads[i] = r[:60] + "R" + r[61:]
+        elif k == 2:
+            reads[i] = r[:100 + (i % 400)]
+        elif k == 3:
+            reads[i] = r[:-30] + "n" + r[-29:]
+        else:
+            reads[i] = r.lower()
+    reads[7], reads[8], reads[9] = "", "N" * 400, "ACGT" * 100
+    d = det.descriptor(ends=ends)
+    want, want_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
+    bases, offsets = native.pack_reads(reads)
+    got = {}
+    for off in (None, "1"):
+        if off:
+            monkeypatch.setenv("QCAT_HIP_NO_BITSLICE", off)
+        cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+        got[off] = native.NativeContext(0).scan(native.NativeKit(d), bases, offsets, counts=cnt)
+        bad = np.nonzero(got[off] != want)[0]
+        assert len(bad) == 0, (off, bad[:10], got[off][bad[:3]], want[bad[:3]])
+        assert np.array_equal(cnt, want_cnt)
+
+
 def test_timing_ring_and_stream_accessor():
     """qcat_ctx_last_timing averages over the scans since the previous call (no sync between scans);
     qcat_ctx_stream hands out the context's stream for stream-ordered RCCL calls."""
