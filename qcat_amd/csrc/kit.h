@@ -57,7 +57,11 @@ struct DevSet {
     int32_t bs_off;             // ids blob: per barcode the target letters as bit words (letter bit 1 lo, hi, letter bit 0 lo, hi)
                                 // for the bit-sliced kernels (kernels_bitslice.inc); -1: set not eligible
     int32_t hot_len;            // the region length almost every job of this set has: barcode + 2 * extension + 1
+    int32_t bs_pre;             // bit-sliced kernels: leading columns every barcode of the set shares (0, 4, 8 or 11 context letters)
+    int32_t bs_rev;             // ... rows and target letters run backwards (the downstream context is the longer one)
 };
+
+constexpr int BS_C_MIN = 20, BS_C_MAX = 48;    // own columns (tlen - bs_pre) the bit-sliced kernels are instantiated for
 
 // work units of a static-letter barcode group per tile: chunks of quads first, then chunks of the pairs left over
 inline int static_units(int n_quads, int n_pairs, int chunk_b) {

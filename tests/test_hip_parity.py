@@ -394,8 +394,8 @@ def test_zero_scores_take_the_sequential_argmax(mode, kit, monkeypatch):
 def test_bit_sliced_barcode_kernels_equal_the_binary16_kernels_and_the_oracle(mode, kit, ends, monkeypatch):
     """Large batches send the full super-tiles of the two hot region lengths through the bit-sliced kernels
     (kernels_bitslice.inc) and the rest through the packed-binary16 kernels; both must give the oracle's records.
-    The batch mixes plain reads (hot), reads with N (hot: N matches nothing), reads with letters outside the
-    alphabet (never hot), truncated reads (other lengths) and degenerate ones."""
+    The batch mixes plain reads (hot), reads with N or letters outside the alphabet (never hot), truncated reads
+    (other lengths) and degenerate ones.  The timing ring must show that the bit-sliced kernels really ran."""
     det = scanner.factory(mode=mode, kit=kit)
     t5 = len(det.layouts) - 1 if kit else (3 if mode == "epi2me" else 1)
     t3 = 0 if len(det.layouts) > 1 else -1
@@ -425,7 +425,15 @@ def test_bit_sliced_barcode_kernels_equal_the_binary16_kernels_and_the_oracle(mo
         if off:
             monkeypatch.setenv("QCAT_HIP_NO_BITSLICE", off)
         cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
-        got[off] = native.NativeContext(0).scan(native.NativeKit(d), bases, offsets, counts=cnt)
+        ctx = native.NativeContext(0)
+        lib = native.HipLibrary.get().lib
+        native.HipLibrary.get().check(lib.qcat_ctx_set_timing(ctx.handle, 1))
+        got[off] = ctx.scan(native.NativeKit(d), bases, offsets, counts=cnt)
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        k = lib.qcat_ctx_last_timing(ctx.handle, names, ms, 16)
+        ran = [names[i].decode() for i in range(k)]
+        assert ("k_barcode_bitslice" in ran) == (off is None), (off, ran)
         bad = np.nonzero(got[off] != want)[0]
         assert len(bad) == 0, (off, bad[:10], got[off][bad[:3]], want[bad[:3]])
         assert np.array_equal(cnt, want_cnt)
