@@ -193,7 +193,8 @@ typedef struct qcat_kit_info {
     int32_t packed, barcode_f16, adapter_f16;
     int32_t n_templates, n_static_templates;
     int32_t n_groups, n_static_groups;
-    int32_t reserved;
+    int32_t bitslice_groups;    /* low 16 bits: groups the bit-sliced barcode kernels take (big batches);
+                                   high 16 bits: those of them with the target letters compiled in */
 } qcat_kit_info;
 int  qcat_kit_describe(const qcat_kit* kit, qcat_kit_info* out);
 

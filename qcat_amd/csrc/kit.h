@@ -59,6 +59,8 @@ struct DevSet {
     int32_t hot_len;            // the region length almost every job of this set has: barcode + 2 * extension + 1
     int32_t bs_pre;             // bit-sliced kernels: leading columns every barcode of the set shares (0, 4, 8 or 11 context letters)
     int32_t bs_rev;             // ... rows and target letters run backwards (the downstream context is the longer one)
+    int32_t bs_kernel;          // bit-sliced kernel with this set's letters compiled in (static_generated.inc / run-time code), -1: none
+    int32_t bs_case_off;        // ids blob: per barcode its case of that kernel
 };
 
 constexpr int BS_C_MIN = 20, BS_C_MAX = 48;    // own columns (tlen - bs_pre) the bit-sliced kernels are instantiated for

@@ -79,15 +79,15 @@ struct KitOnDevice {
     char* ascii = nullptr;
     // static-letter kernels compiled for this kit at run time (qcat_kit_attach_code)
     hipModule_t jit_module = nullptr;
-    hipFunction_t jit_ad[MAX_T] = {}, jit_am[MAX_T] = {}, jit_bc[MAX_T * 2] = {};
+    hipFunction_t jit_ad[MAX_T] = {}, jit_am[MAX_T] = {}, jit_bc[MAX_T * 2] = {}, jit_bs[MAX_T * 2] = {};
 };
 
 struct qcat_kit {
     HostKit hk;
     std::mutex mu;
     KitOnDevice dev[MAX_DEVICES];
-    std::vector<uint8_t> jit_code;                 // code object (gfx950) with qj_ad_<t>, qj_am_<t>, qj_bc_<t*2+s>
-    bool jit_tpl[MAX_T] = {}, jit_grp[MAX_T * 2] = {};
+    std::vector<uint8_t> jit_code;                 // code object (gfx950) with qj_ad_<t>, qj_am_<t>, qj_bc_<t*2+s>, qj_bs_<t*2+s>
+    bool jit_tpl[MAX_T] = {}, jit_grp[MAX_T * 2] = {}, jit_bsgrp[MAX_T * 2] = {};
 };
 
 // launch of a run-time generated kernel (kernel id >= QCAT_JIT_BASE): the scan in progress on this
@@ -97,10 +97,12 @@ static thread_local const KitOnDevice* g_jit = nullptr;
 namespace qk {
 static inline void jit_launch(int kind, int index, dim3 grid, hipStream_t stream, const void* args) {
     hipFunction_t f = nullptr;
-    if (g_jit) f = kind == QCAT_JIT_ADAPTER ? g_jit->jit_ad[index] : (kind == QCAT_JIT_MIDDLE ? g_jit->jit_am[index] : g_jit->jit_bc[index]);
+    if (g_jit) f = kind == QCAT_JIT_ADAPTER ? g_jit->jit_ad[index] : (kind == QCAT_JIT_MIDDLE ? g_jit->jit_am[index] :
+                   (kind == QCAT_JIT_BITSLICE ? g_jit->jit_bs[index] : g_jit->jit_bc[index]));
     if (!f) { g_packed_err = "run-time generated kernel missing from the kit's code object"; g_jit_rc = QCAT_ERR_DEVICE; return; }
     void* params[1] = {const_cast<void*>(args)};
-    const hipError_t e = hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, PK_WAVES * 64, 1, 1, 0, stream, params, nullptr);
+    const unsigned threads = kind == QCAT_JIT_BITSLICE ? BS_WAVES * 64 : PK_WAVES * 64;
+    const hipError_t e = hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, threads, 1, 1, 0, stream, params, nullptr);
     if (e != hipSuccess) { g_packed_err = std::string("launch of a run-time generated kernel: ") + hipGetErrorString(e); g_jit_rc = QCAT_ERR_DEVICE; }
 }
 }  // namespace qk
@@ -202,6 +204,16 @@ extern "C" int qcat_kit_attach_code_quads(qcat_kit* k, const void* code, uint64_
             }
             k->jit_grp[t * 2 + s] = true;
         }
+        // bit 1 of a group flag: the code object also holds qj_bs_<group>, the bit-sliced kernel with this set's
+        // letters compiled in (case = barcode index); only sets the bit-sliced path takes at all can use it
+        for (int s = 0; s < nsets; ++s) {
+            DevSet& q = d.tpl[t].sets[s];
+            if (!(group_flags[t * 2 + s] & 2) || q.bs_off < 0 || q.bs_kernel >= 0 || q.n <= 0) continue;
+            q.bs_kernel = QCAT_JIT_BASE + t * 2 + s;
+            q.bs_case_off = (int32_t)h.ids.size();
+            for (int b = 0; b < q.n; ++b) h.ids.push_back(b);
+            k->jit_bsgrp[t * 2 + s] = true;
+        }
     }
     return 0;
 }
@@ -219,6 +231,7 @@ extern "C" int qcat_kit_describe(const qcat_kit* k, qcat_kit_info* out) {
         for (int s = 0; s < nsets; ++s) {
             out->n_groups++;
             if (d.tpl[t].sets[s].static_kernel >= 0) out->n_static_groups++;
+            if (d.bs_ok && d.tpl[t].sets[s].bs_off >= 0) out->bitslice_groups += d.tpl[t].sets[s].bs_kernel >= 0 ? 0x10001 : 1;
         }
     }
     return 0;
@@ -273,6 +286,10 @@ static int kit_upload(qcat_kit* k, KitOnDevice& kd) {
             for (int s2 = 0; s2 < 2; ++s2) if (k->jit_grp[t * 2 + s2]) {
                 snprintf(name, sizeof name, "qj_bc_%d", t * 2 + s2);
                 HIPCHK(hipModuleGetFunction(&kd.jit_bc[t * 2 + s2], kd.jit_module, name));
+            }
+            for (int s2 = 0; s2 < 2; ++s2) if (k->jit_bsgrp[t * 2 + s2]) {
+                snprintf(name, sizeof name, "qj_bs_%d", t * 2 + s2);
+                HIPCHK(hipModuleGetFunction(&kd.jit_bs[t * 2 + s2], kd.jit_module, name));
             }
         }
     }

@@ -230,8 +230,47 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
             entry.append('extern "C" __global__ void __launch_bounds__(qk::PK_WAVES * 64, %d) '
                          "qj_bc_%d(qk::StaticArgs a) { qk::barcode_static_body<qk::QSGJ_%d>(a); }\n" % (2 if quad_list else 4, g, g))
             grp_flags[g] = 1
+            # bit-sliced rows with the letters compiled in (kernels_bitslice.inc): case = barcode index
+            shape = _bs_shape(len(up), len(dn), m) if len(targets) <= 128 else None
+            if shape:
+                rev, pre, own = shape
+                parts.append("struct QBSJ_%d {\n    static constexpr int C = %d, KERNEL = QCAT_JIT_BASE + %d;\n"
+                             "    static __device__ __forceinline__ void rows(int kase, const uint4* __restrict__ s_rows, int L, int lane, "
+                             "bool shared, u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n" % (g, own, g))
+                for b, tg in enumerate(targets):
+                    w1, w0 = _bs_words(tg, rev, pre)
+                    parts.append("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(s_rows, L, lane, shared, h1, h0, f); break;\n" % (b, w1, w0))
+                parts.append("        default: break;\n        }\n    }\n};\n")
+                entry.append('extern "C" __global__ void __launch_bounds__(qk::BS_WAVES * 64) '
+                             "qj_bs_%d(qk::BsArgs a) { qk::bs_barcode_body<qk::QBSJ_%d>(a); }\n" % (g, g))
+                grp_flags[g] |= 2
     parts.append("}  // namespace qk\n")
     return "".join(parts + entry), tpl_flags, grp_flags, entries, [[q[:5] for q in g] for g in quads]
+
+
+BS_C_MIN, BS_C_MAX = 20, 48          # kit.h
+
+
+def _bs_shape(uplen, downlen, m):
+    """(reversed, shared columns, own columns) of a set on the bit-sliced kernels, or None -- the rule of
+    kit_prepare.inc: the longer context leads, 11 / 8 / 4 / 0 of its columns are shared"""
+    rev = downlen > uplen
+    lead = downlen if rev else uplen
+    pre = 11 if lead >= 11 else (8 if lead >= 8 else (4 if lead >= 4 else 0))
+    own = m - pre
+    if not (BS_C_MIN <= own <= BS_C_MAX and m <= 64):
+        return None
+    return rev, pre, own
+
+
+def _bs_words(codes, rev, pre):
+    """letter bit words of the own columns in the order the kernel walks them (bit j = own column j)"""
+    t = codes[::-1] if rev else codes
+    w1 = w0 = 0
+    for j, c in enumerate(t[pre:]):
+        w1 |= ((c >> 1) & 1) << j
+        w0 |= (c & 1) << j
+    return w1, w0
 
 
 def _prelude_digest():

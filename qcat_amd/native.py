@@ -180,7 +180,7 @@ class KitInfo(C.Structure):
     """qcat_kit_info (include/qcat_hip.h): which kernels a prepared kit runs."""
     _fields_ = [("packed", C.c_int32), ("barcode_f16", C.c_int32), ("adapter_f16", C.c_int32),
                 ("n_templates", C.c_int32), ("n_static_templates", C.c_int32),
-                ("n_groups", C.c_int32), ("n_static_groups", C.c_int32), ("reserved", C.c_int32)]
+                ("n_groups", C.c_int32), ("n_static_groups", C.c_int32), ("bitslice_groups", C.c_int32)]
 
 
 def pack_reads(read_sequences):
@@ -344,7 +344,7 @@ class NativeKit(object):
         are bound to generated static-letter kernels."""
         info = KitInfo()
         self.hip.check(self.hip.lib.qcat_kit_describe(handle if handle is not None else self.handle, C.byref(info)))
-        return {name: int(getattr(info, name)) for name, _ in KitInfo._fields_ if name != "reserved"}
+        return {name: int(getattr(info, name)) for name, _ in KitInfo._fields_ }
 
     def __del__(self):
         th = getattr(self, "jit_thread", None)

@@ -22,6 +22,8 @@ from qcat_amd import scanner                    # noqa: E402
 
 OUT = os.path.join(ROOT, "qcat_amd", "csrc", "static_generated.inc")
 QUAD_MIN_TARGETS = 48       # families this large also get four-target chains (the big sets dominate the run time)
+BS_MIN_TARGETS = 48         # ... and bit-sliced row loops with the letters compiled in (kernels_bitslice.inc)
+BS_C_MIN, BS_C_MAX = 20, 48 # kit.h
 CODE = {"A": 0, "T": 1, "G": 2, "C": 3}
 ACODE = {"A": 0, "T": 1, "G": 2, "C": 3, "N": 4}        # adapter templates also hold barcode placeholders
 
@@ -50,6 +52,29 @@ def chain(letters, code):
         else:
             out.append("QS_LAST%d(%d%s)" % (k, j + 1, "".join(", " + x for x in inner)))
     return " ".join(out)
+
+
+def bs_shape(uplen, downlen, m):
+    """(reversed, shared columns, own columns) of a target family on the bit-sliced kernels, or None: the rule of
+    kit_prepare.inc (the longer context leads; 11 / 8 / 4 / 0 of its columns are shared)"""
+    rev = downlen > uplen
+    lead = downlen if rev else uplen
+    pre = 11 if lead >= 11 else (8 if lead >= 8 else (4 if lead >= 4 else 0))
+    own = m - pre
+    if not (BS_C_MIN <= own <= BS_C_MAX and m <= 64):
+        return None
+    return rev, pre, own
+
+
+def bs_words(target, rev, pre, code):
+    """letter bit words of the own columns in the order the kernel walks them (bit j = own column j)"""
+    t = target[::-1] if rev else target
+    w1 = w0 = 0
+    for j, ch in enumerate(t[pre:]):
+        c = code[ch]
+        w1 |= ((c >> 1) & 1) << j
+        w0 |= (c & 1) << j
+    return w1, w0
 
 
 def pair_up(targets, flank):
@@ -126,6 +151,7 @@ def render():
     """text of static_generated.inc plus (n kernels, n targets, n templates)"""
     fams, templates, fused, members = collect()
     reg = []
+    bs_fams = []                                     # (kernel, upstream columns, downstream columns, has bit-sliced rows)
     quad_reg = []                                    # (kernel, quad case, pair a, pair b)
     fh = _Buf()
     if True:
@@ -190,7 +216,25 @@ def render():
             for pr, (ta, tb, up_) in enumerate(pairs):
                 fh.write("        case %d: static_barcode_rows2<M, %d, QSP_%d_%d>(qbuf, lane, Lmax, gL2, special, ltr, rowoff, coloff, ra, rb); break;\n"
                          % (pr, up_, kid, pr))
-            fh.write("        default: break;\n        }\n    }\n};\n\n")
+            fh.write("        default: break;\n        }\n    }\n};\n")
+            shape = bs_shape(len(up), len(dn), m) if len(targets) >= BS_MIN_TARGETS else None
+            bs_fams.append((kid, len(up), len(dn), shape is not None))
+            if shape:
+                rev, pre, own = shape
+                fh.write("struct QBS_%d {      // bit-sliced rows, letters compiled in: %s, %d shared + %d own columns\n"
+                         % (kid, "reversed" if rev else "forward", pre, own))
+                fh.write("    static constexpr int C = %d, KERNEL = %d;\n" % (own, kid))
+                fh.write("    static __device__ __forceinline__ void rows(int kase, const uint4* __restrict__ s_rows, int L, int lane, bool shared, "
+                         "u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n")
+                for pr, (ta, tb, up_) in enumerate(pairs):
+                    for half, t in ((0, ta), (1, tb)):
+                        if half == 1 and tb == ta:
+                            continue
+                        w1, w0 = bs_words(t, rev, pre, CODE)
+                        fh.write("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(s_rows, L, lane, shared, h1, h0, f); break;\n"
+                                 % (2 * pr + half, w1, w0))
+                fh.write("        default: break;\n        }\n    }\n};\n")
+            fh.write("\n")
         reg.sort()
         assert len(set(h for h, _, _, _ in reg)) == len(reg), "hash collision between targets"
         fh.write("// (the hash only finds the entry; static_match compares `seq` with the kit's target before binding)\n")
@@ -200,6 +244,10 @@ def render():
             fh.write("    {0x%016XULL, %d, %d, \"%s\"},\n" % (h, kid, case, seq))
         fh.write("};\nstatic const int g_n_static_targets = %d;\n" % len(reg))
         fh.write("static const int g_static_kernel_M[] = {%s};\n" % ", ".join(str(m) for (_, _, m) in fams))
+        fh.write("// per kernel: upstream / downstream context columns of the family, and whether it has bit-sliced rows (QBS_n)\n")
+        fh.write("static const int g_static_kernel_up[] = {%s};\n" % ", ".join(str(u) for (_, u, _, _) in bs_fams))
+        fh.write("static const int g_static_kernel_dn[] = {%s};\n" % ", ".join(str(d) for (_, _, d, _) in bs_fams))
+        fh.write("static const int g_static_kernel_bs[] = {%s};\n" % ", ".join("1" if b else "0" for (_, _, _, b) in bs_fams))
         fh.write("// quads of a kernel: (kernel, quad case, pair case a, pair case b); a kit group runs them when it scans both pairs\n")
         fh.write("struct StaticQuad { int16_t kernel, quad, pair_a, pair_b; };\n")
         fh.write("static const StaticQuad g_static_quads[] = {\n")
@@ -211,6 +259,13 @@ def render():
                  "    switch (kernel) {\n")
         for kid in range(len(fams)):
             fh.write("    case %d: hipLaunchKernelGGL(k_barcode_static<QSG_%d>, grid, dim3(PK_WAVES * 64), 0, stream, a); break;\n" % (kid, kid))
+        fh.write("    default: break;\n    }\n}\n\n")
+        fh.write("static inline void launch_bs_static(int kernel, dim3 grid, hipStream_t stream, const BsArgs& a) {\n"
+                 "    if (kernel >= QCAT_JIT_BASE) { jit_launch(QCAT_JIT_BITSLICE, kernel - QCAT_JIT_BASE, grid, stream, &a); return; }\n"
+                 "    switch (kernel) {\n")
+        for kid, _, _, has in bs_fams:
+            if has:
+                fh.write("    case %d: hipLaunchKernelGGL(k_bs_barcode<QBS_%d>, grid, dim3(BS_WAVES * 64), 0, stream, a); break;\n" % (kid, kid))
         fh.write("    default: break;\n    }\n}\n\n")
         # ---- adapter templates ------------------------------------------------------------------
         areg = []
