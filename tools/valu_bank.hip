@@ -51,10 +51,12 @@ template <int MODE> void run(const char* name, unsigned* d, int blocks_per_cu) {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double insts = (double)blocks * 4 * ITERS * 64.0;
     double per = insts / (ms * 1e-3) / (256 * 4);
-    printf("%-52s %d waves/SIMD %8.3f ms  %.2f cycles/inst @2.4GHz\n", name, blocks_per_cu, ms, 2.4e9 / per);
+    printf("%-52s %3d blocks/CU %8.3f ms  %.2f cycles/inst @2.4GHz\n", name, blocks_per_cu, ms, 2.4e9 / per);
 }
 int main() {
-    unsigned* d; hipMalloc(&d, 256 * 8 * 256 * 4);
+    unsigned* d; hipMalloc(&d, 256 * 256 * 256 * 4);
+    // sustained rate: the same kernel for tens of milliseconds (8 waves per SIMD resident, 32x the blocks)
+    run<0>("3 sources, 3 banks, long run", d, 8); run<0>("3 sources, 3 banks, long run", d, 256); run<0>("3 sources, 3 banks, long run", d, 256);
     for (int w : {8, 2, 1}) {
         if (w == 8) { run<0>("3 sources, 3 banks", d, 8); run<1>("src1, src2 same bank", d, 8); run<3>("src0, src1 same bank", d, 8); run<2>("all same bank", d, 8); run<5>("2 VGPR + SGPR", d, 8); run<6>("dst != src0, 3 banks", d, 8); run<4>("one dependent chain", d, 8); }
         if (w == 2) { run<0>("3 sources, 3 banks", d, 2); run<1>("src1, src2 same bank", d, 2); run<3>("src0, src1 same bank", d, 2); run<2>("all same bank", d, 2); run<5>("2 VGPR + SGPR", d, 2); run<6>("dst != src0, 3 banks", d, 2); run<4>("one dependent chain", d, 2); }
