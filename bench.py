@@ -218,13 +218,15 @@ def main():
                     "algorithmic_bytes_per_launch": a.reads * bytes_per_read,
                     "avg_launch_ms": round(avg[dom], 4),
                     "kernels_avg_ms": {k: round(v, 4) for k, v in avg.items()},
-                    "note": "integer DP (u16 and exact-integer fp16 lanes): VALU-issue bound, not HBM bound (SURVEY.md 8d); see valu"}
+                    "note": "integer DP (bit-sliced boolean planes for the barcode scan, exact-integer fp16 / u16 lanes for the rest): "
+                            "VALU-issue bound, not HBM bound (SURVEY.md 8d); see valu"}
         out = {"metric": "reads/sec demultiplexed", "value": round(value, 1), "unit": "reads/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
-               "dtype": "int16 (the reference's int32 DP in 16-bit lanes -- u16 / exact-integer f16 -- proven exact per kit "
-                        "by a range bound at kit creation; kits outside the bound run the int32 kernel)",
+               "dtype": "int16 / bit planes (the reference's int32 DP as differences of neighbouring cells in two boolean planes "
+                        "for the barcode scan, in 16-bit lanes -- u16 / exact-integer f16 -- for the adapter scan; both proven exact "
+                        "per kit by range bounds at kit creation; kits outside the bounds run the int32 kernel)",
                "data": "synthetic",
                "config": {"workload": "%s: %d synthetic reads/GPU, kit %s (%s), %s, error rate %.2f, "
                                       "~%d nt reads" % (a.workload, a.reads, kit_name or "DUAL", mode,
@@ -240,6 +242,8 @@ def main():
         info = kit.describe()
         out["kernels"] = {"static_templates": "%d/%d" % (info["n_static_templates"], info["n_templates"]),
                           "static_barcode_groups": "%d/%d" % (info["n_static_groups"], info["n_groups"]),
+                          "bitsliced_barcode_groups": "%d/%d (%d with the target letters compiled in)"
+                                                      % (info["bitslice_groups"] & 0xFFFF, info["n_groups"], info["bitslice_groups"] >> 16),
                           "kit_prepare_s": round(kit_seconds, 2)}
         if "rccl_counts_allreduce" in avg:
             out["count_allreduce_ms"] = round(avg["rccl_counts_allreduce"], 4)
@@ -340,31 +344,40 @@ def cpu_legs(a, out, lib, kit, sp, desc, det, cfg, mode, recs, avg, elapsed):
     # VALU-issue ceilings: one wave retires 128 cells per column; cycles per column from the issue
     # rates tools/valu_rate.hip measures on this chip (profiles/r01_valu_issue_rates.txt)
     simd_hz = 256 * 4 * 2.4e9
+    bs_static = (kit.describe()["bitslice_groups"] >> 16) > 0
     cyc = {"k_adapter_packed": 4.17 + 2.73 + 4.15 + 4.15,    # v_perm_b32 + v_add_u32 + 2 x v_pk_max_u16 (u16 lanes)
            "k_barcode_packed": 4.17 + 4.18 + 4.20,           # v_perm_b32 + v_pk_add_f16 + v_pk_maximum3_f16
            "k_adapter_static": 4.18 + 4.20,                  # v_pk_add_f16 + v_pk_maximum3_f16 (static letters)
-           "k_barcode_static": 4.18 + 4.20}
+           "k_barcode_static": 4.18 + 4.20,
+           # bit-sliced: 2048 cells per wave-column = 16 x 128; seven v_bitop3_b32 with VGPR sources at 2.04 cycles
+           # (sustained, tools/valu_bank.hip), + two with an SGPR source at 4.15 when the letters come from memory
+           "k_barcode_bitslice": (7 * 2.04 + (0 if bs_static else 2 * 4.15)) / 16.0}
     valu = {"unit": "DP cell updates/s", "dp_cells_per_read": round(cells_a + cells_b, 1),
             "region_path_fraction": round(region_frac, 4)}
     ideal_s = 0.0
     for name, cells, kerns in (("adapter", cells_a, ("k_adapter_static", "k_adapter_packed")),
-                               ("barcode", cells_b, ("k_barcode_static", "k_barcode_packed"))):
+                               ("barcode", cells_b, ("k_barcode_bitslice", "k_barcode_static", "k_barcode_packed"))):
         ran = [kn for kn in kerns if kn in avg]
         if not ran:
             continue
         ms = sum(avg[kn] for kn in ran)
-        ceil = simd_hz * 128 / max(cyc[kn] for kn in ran)      # mixed kits: priced at the slower instruction mix
+        # the bit-sliced kernels take all but the odd lengths and the last jobs of a class: the phase is priced at
+        # their rate when they ran; otherwise (mixed kits) at the slower instruction mix
+        ceil = simd_hz * 128 / (cyc["k_barcode_bitslice"] if "k_barcode_bitslice" in ran else max(cyc[kn] for kn in ran))
         per_launch = cells * a.reads
         ideal_s += per_launch / ceil
         valu[name] = {"kernels": ran, "cells_per_read": round(cells, 1), "kernel_ms": round(ms, 4), "ceiling": round(ceil, 1),
                       "achieved": round(per_launch / (ms * 1e-3), 1), "frac": round(per_launch / (ms * 1e-3) / ceil, 4)}
     valu["frac_of_valu_peak"] = round(ideal_s / (elapsed / a.steps), 4)
     valu["note"] = ("ceiling = 1024 SIMDs x 2.4 GHz x 128 cells per wave-column / VALU issue cycles per column "
-                    "(issue rates measured by tools/valu_rate.hip, profiles/r01_valu_issue_rates.txt): static-letter kernels "
-                    "v_pk_add_f16 + v_pk_maximum3_f16 = 8.38 cycles; table kernels 12.55 (fp16 lanes) / 15.2 (u16 lanes); "
-                    "frac_of_valu_peak = ideal DP time of both phases / whole step time.  Cells are the "
-                    "reference-defined ones (SURVEY.md 8d); the barcode chains run two or four targets per row pass "
-                    "and compute the columns they share (at least the upstream flank) once, so `barcode.frac` can exceed 1")
+                    "(issue rates measured by tools/valu_rate.hip and tools/valu_bank.hip, profiles/r01_valu_issue_rates.txt, "
+                    "profiles/r02_valu_operand_rates.txt).  Bit-sliced barcode kernels: seven v_bitop3_b32 per 2048 cells at 2.04 "
+                    "cycles (+ two SGPR-source ones at 4.15 when the letters come from memory) = 0.89 (1.41) cycles per 128 cells; "
+                    "static-letter fp16 kernels v_pk_add_f16 + v_pk_maximum3_f16 = 8.38 cycles; table kernels 12.55 (fp16 lanes) / "
+                    "15.2 (u16 lanes); frac_of_valu_peak = ideal DP time of both phases / whole step time.  Cells are the "
+                    "reference-defined ones (SURVEY.md 8d); the bit-sliced kernels compute the longer context's columns once per "
+                    "2048 alignments (11 of PBC096's 42), the fp16 chains the columns their two or four targets share, so "
+                    "`barcode.frac` counts more cells than the kernels evaluate")
     out["valu"] = valu
 
 

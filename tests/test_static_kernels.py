@@ -28,8 +28,9 @@ def _generator():
 
 def test_generated_source_is_in_sync_with_the_kit_bundle():
     gen = _generator()
-    text, n_kernels, n_targets, n_templates = gen.render()
+    text, n_kernels, n_targets, n_templates, bs_text = gen.render()
     assert open(gen.OUT).read() == text, "run python tools/gen_static_kernels.py"
+    assert open(gen.BS_OUT).read() == bs_text, "run python tools/gen_static_kernels.py"
     assert n_kernels >= 16 and n_targets >= 600 and n_templates >= 14
 
 

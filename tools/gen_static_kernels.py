@@ -22,8 +22,10 @@ from qcat_amd import scanner                    # noqa: E402
 
 OUT = os.path.join(ROOT, "qcat_amd", "csrc", "static_generated.inc")
 QUAD_MIN_TARGETS = 48       # families this large also get four-target chains (the big sets dominate the run time)
-BS_MIN_TARGETS = 48         # ... and bit-sliced row loops with the letters compiled in (kernels_bitslice.inc)
+BS_MIN_TARGETS = 12         # families this large get bit-sliced row loops with the letters compiled in (kernels_bitslice.inc)
 BS_C_MIN, BS_C_MAX = 20, 48 # kit.h
+BS_PARTS = 6                # translation units the bit-sliced static-letter kernels are split over (__graft_entry__.build)
+BS_OUT = os.path.join(ROOT, "qcat_amd", "csrc", "bs_static_generated.inc")
 CODE = {"A": 0, "T": 1, "G": 2, "C": 3}
 ACODE = {"A": 0, "T": 1, "G": 2, "C": 3, "N": 4}        # adapter templates also hold barcode placeholders
 
@@ -152,6 +154,7 @@ def render():
     fams, templates, fused, members = collect()
     reg = []
     bs_fams = []                                     # (kernel, upstream columns, downstream columns, has bit-sliced rows)
+    bs_structs = []                                  # (kernel, targets, text of its QBS struct) -> bs_static_generated.inc
     quad_reg = []                                    # (kernel, quad case, pair a, pair b)
     fh = _Buf()
     if True:
@@ -221,19 +224,21 @@ def render():
             bs_fams.append((kid, len(up), len(dn), shape is not None))
             if shape:
                 rev, pre, own = shape
-                fh.write("struct QBS_%d {      // bit-sliced rows, letters compiled in: %s, %d shared + %d own columns\n"
-                         % (kid, "reversed" if rev else "forward", pre, own))
-                fh.write("    static constexpr int C = %d, KERNEL = %d;\n" % (own, kid))
-                fh.write("    static __device__ __forceinline__ void rows(int kase, const uint4* __restrict__ s_rows, int L, int lane, bool shared, "
+                bh = _Buf()
+                bh.write("struct QBS_%d {      // %s + barcode + %s: %s, %d shared + %d own columns, %d targets\n"
+                         % (kid, up, dn, "reversed" if rev else "forward", pre, own, len(targets)))
+                bh.write("    static constexpr int C = %d, KERNEL = %d;\n" % (own, kid))
+                bh.write("    static __device__ __forceinline__ void rows(int kase, const uint4* __restrict__ s_rows, int L, int lane, bool shared, "
                          "u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n")
                 for pr, (ta, tb, up_) in enumerate(pairs):
                     for half, t in ((0, ta), (1, tb)):
                         if half == 1 and tb == ta:
                             continue
                         w1, w0 = bs_words(t, rev, pre, CODE)
-                        fh.write("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(s_rows, L, lane, shared, h1, h0, f); break;\n"
+                        bh.write("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(s_rows, L, lane, shared, h1, h0, f); break;\n"
                                  % (2 * pr + half, w1, w0))
-                fh.write("        default: break;\n        }\n    }\n};\n")
+                bh.write("        default: break;\n        }\n    }\n};\n")
+                bs_structs.append((kid, len(targets), "".join(bh.parts)))
             fh.write("\n")
         reg.sort()
         assert len(set(h for h, _, _, _ in reg)) == len(reg), "hash collision between targets"
@@ -260,13 +265,38 @@ def render():
         for kid in range(len(fams)):
             fh.write("    case %d: hipLaunchKernelGGL(k_barcode_static<QSG_%d>, grid, dim3(PK_WAVES * 64), 0, stream, a); break;\n" % (kid, kid))
         fh.write("    default: break;\n    }\n}\n\n")
+        # the bit-sliced static-letter kernels are compiled in translation units of their own (bs_static.hip with
+        # QCAT_BS_PART = 0..BS_PARTS-1, in parallel with this one): greedy split by number of targets
+        parts = [[] for _ in range(BS_PARTS)]
+        for kid, nt, text in sorted(bs_structs, key=lambda x: -x[1]):
+            min(parts, key=lambda p: sum(n for _, n, _ in p)).append((kid, nt, text))
+        fh.write("}  // namespace qk\n")
+        for p in range(BS_PARTS):
+            fh.write('extern "C" void qcat_bs_launch_part%d(int kernel, unsigned grid, void* stream, const void* args);   // bs_static.hip\n' % p)
+        fh.write("namespace qk {\n")
         fh.write("static inline void launch_bs_static(int kernel, dim3 grid, hipStream_t stream, const BsArgs& a) {\n"
                  "    if (kernel >= QCAT_JIT_BASE) { jit_launch(QCAT_JIT_BITSLICE, kernel - QCAT_JIT_BASE, grid, stream, &a); return; }\n"
                  "    switch (kernel) {\n")
-        for kid, _, _, has in bs_fams:
-            if has:
-                fh.write("    case %d: hipLaunchKernelGGL(k_bs_barcode<QBS_%d>, grid, dim3(BS_WAVES * 64), 0, stream, a); break;\n" % (kid, kid))
+        for p, part in enumerate(parts):
+            if part:
+                fh.write("    %s qcat_bs_launch_part%d(kernel, grid.x, stream, &a); break;\n"
+                         % (" ".join("case %d:" % kid for kid, _, _ in sorted(part)), p))
         fh.write("    default: break;\n    }\n}\n\n")
+        bparts = ["// GENERATED by tools/gen_static_kernels.py -- do not edit.\n"
+                  "// Bit-sliced barcode kernels with the target letters compiled in (kernels_bitslice.inc), one struct per target\n"
+                  "// family; compiled by bs_static.hip in %d parts (QCAT_BS_PART), each in its own namespace.\n\n" % BS_PARTS]
+        for p, part in enumerate(parts):
+            bparts.append("#if QCAT_BS_PART == %d\nnamespace qk {\n" % p)
+            for kid, _, text in sorted(part):
+                bparts.append(text)
+            bparts.append("}  // namespace qk\n")
+            bparts.append('extern "C" void qcat_bs_launch_part%d(int kernel, unsigned grid, void* stream, const void* args) {\n'
+                          "    const qk::BsArgs& a = *static_cast<const qk::BsArgs*>(args);\n    switch (kernel) {\n" % p)
+            for kid, _, _ in sorted(part):
+                bparts.append("    case %d: hipLaunchKernelGGL(qk::k_bs_barcode<qk::QBS_%d>, dim3(grid), dim3(qk::BS_WAVES * 64), 0, "
+                              "static_cast<hipStream_t>(stream), a); break;\n" % (kid, kid))
+            bparts.append("    default: break;\n    }\n}\n#endif\n\n")
+        bs_text = "".join(bparts)
         # ---- adapter templates ------------------------------------------------------------------
         areg = []
         for tid, seq in enumerate(templates):
@@ -322,13 +352,15 @@ def render():
             fh.write("    case %d: hipLaunchKernelGGL((k_adapter_middle<%d, QAC_%d>), grid, dim3(PK_WAVES * 64), 0, stream, a); break;\n"
                      % (tid, len(seq), tid))
         fh.write("    default: break;\n    }\n}\n#endif\n\n}  // namespace qk\n")
-    return "".join(fh.parts), len(fams), len(reg), len(templates)
+    return "".join(fh.parts), len(fams), len(reg), len(templates), bs_text
 
 
 def main():
-    text, nk, nt, na = render()
+    text, nk, nt, na, bs_text = render()
     with open(OUT, "w") as out:
         out.write(text)
+    with open(BS_OUT, "w") as out:
+        out.write(bs_text)
     print("wrote %s: %d barcode kernels, %d targets, %d adapter templates" % (OUT, nk, nt, na))
 
 

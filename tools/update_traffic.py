@@ -9,22 +9,27 @@ tag = sys.argv[1]
 out = {"_comment": "HBM traffic of the dominant kernel per launch, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
        "passes, tools/profile.sh; per-dispatch averages in profiles/%s_*/summary.txt). bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: "
        "FETCH_SIZE/WRITE_SIZE are in KiB and gfx950's FETCH_SIZE reports half of a wide coalesced read stream "
-       "(MI355X_MICROARCH.md, HBM section); all instantiations of the barcode DP kernel that ran in the step (static-letter kernels of every group, table kernels of every width class) are summed." % tag}
+       "(MI355X_MICROARCH.md, HBM section); all kernels of the dominant timing mark that ran in the step are summed (bit-sliced: k_bs_barcode of every family + k_bs_select + k_bs_plan; else the static-letter kernels of every group and the table kernels of every width class)." % tag}
 for arg in sys.argv[2:]:
     wl, d = arg.split("=")
     reads = 1000000
     if ":" in d:
         d, r = d.rsplit(":", 1)
         reads = int(r)
+    # the dominant mark of the step: the bit-sliced barcode kernels when they ran, else the packed-binary16 ones
+    with open(os.path.join(d, "pmc3.csv")) as fh:
+        bitsliced = any("k_bs_barcode" in row["Kernel_Name"] for row in csv.DictReader(fh))
+    pats = ("k_bs_barcode", "k_bs_select", "k_bs_plan") if bitsliced else ("k_barcode_packed", "k_barcode_static")
     tot = defaultdict(float)
     for name, fn in (("FETCH_SIZE", "pmc3.csv"), ("WRITE_SIZE", "pmc4.csv")):
         per = defaultdict(list)
         with open(os.path.join(d, fn)) as fh:
             for row in csv.DictReader(fh):
-                if ("k_barcode_packed" in row["Kernel_Name"] or "k_barcode_static" in row["Kernel_Name"]) and row["Counter_Name"] == name:
+                if any(p in row["Kernel_Name"] for p in pats) and row["Counter_Name"] == name:
                     per[row["Kernel_Name"]].append(float(row["Counter_Value"]))
         tot[name] = sum(sum(v) / len(v) for v in per.values())
-    out[wl] = {"kernel": "k_barcode_static+k_barcode_packed", "reads_per_launch": reads, "fetch_size_kib": round(tot["FETCH_SIZE"], 1),
+    out[wl] = {"kernel": "k_barcode_bitslice (k_bs_barcode + k_bs_select + k_bs_plan)" if bitsliced else "k_barcode_static+k_barcode_packed",
+               "reads_per_launch": reads, "fetch_size_kib": round(tot["FETCH_SIZE"], 1),
                "write_size_kib": round(tot["WRITE_SIZE"], 1), "bytes": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024)}
 with open(os.path.join(ROOT, "profiles", tag + "_traffic.json"), "w") as fh:
     json.dump(out, fh, indent=1)
