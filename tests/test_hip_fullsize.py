@@ -172,6 +172,7 @@ def test_config5_dual_one_million_reads(which, tmp_path):
     try:
         info = r.kit.describe()
         assert info["packed"] == 1 and info["n_static_groups"] == info["n_groups"] == 4      # static-letter kernels either way
+        assert info["bitslice_groups"] == 4 * 0x10001           # ... and bit-sliced ones with the letters compiled in
         recs, cnt = r.scan()
         nb = len(r.desc.slot_ids)
         assert cnt[:nb * nb + 1].sum() == r.n and cnt[nb * nb + 1:-1].sum() == r.n and cnt[-1] == 0            # histogram = records

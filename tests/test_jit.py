@@ -49,6 +49,8 @@ def test_generated_unit_compiles_and_binds_everything(tmp_path):
         info = native.NativeKit(det.descriptor(), jit=True).describe()
         assert info["n_static_templates"] == info["n_templates"] == nt
         assert info["n_static_groups"] == info["n_groups"] == ng
+        # ... and the bit-sliced kernels of every group have the kit's letters compiled in (qj_bs_<group>)
+        assert plain["bitslice_groups"] == ng and info["bitslice_groups"] == ng * 0x10001
 
 
 @pytest.mark.skipif(jit.hiprtc() is None or jit.hipcc_path() is None, reason="needs both libhiprtc and hipcc")
@@ -63,7 +65,7 @@ def test_hiprtc_and_hipcc_both_produce_loadable_units(tmp_path, monkeypatch):
     b = jit._compile_hipcc(source)
     for blob in (a, b):
         assert blob[:4] in (b"\x7fELF", b"__CL") and len(blob) > 10000      # code object or clang offload bundle
-        for sym in (b"qj_ad_0", b"qj_am_0", b"qj_bc_0", b"qj_bc_1"):
+        for sym in (b"qj_ad_0", b"qj_am_0", b"qj_bc_0", b"qj_bc_1", b"qj_bs_0", b"qj_bs_1"):
             assert sym in blob
     monkeypatch.setenv("QCAT_AMD_JIT_COMPILER", "hipcc")
     assert jit.compiler() == "hipcc"
