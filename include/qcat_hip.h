@@ -214,7 +214,10 @@ int  qcat_kit_attach_code(qcat_kit* kit, const void* code, uint64_t size,
 
 /* The same with four-target chains: group g may also export cases of qj_bc_<g>'s run4 switch; quad_entries holds, at
  * [quad_offsets[g], quad_offsets[g+1]), the 5-tuples (quad case, kit barcodes a, b, c, d -- all present).  Every barcode
- * of a flagged group must appear exactly once over its pair and quad lists.  quad_offsets == NULL: no quads. */
+ * of a flagged group must appear exactly once over its pair and quad lists.  quad_offsets == NULL: no quads.
+ * Bit 1 of group_flags[g] (value 2 or 3): the code object also exports qj_bs_<g>, the bit-sliced barcode kernel of the
+ * group with its target letters compiled in (case = barcode index of the set; kernels_bitslice.inc); it is bound when the
+ * kit's set takes the bit-sliced path at all (qcat_kit_info.bitslice_groups). */
 int  qcat_kit_attach_code_quads(qcat_kit* kit, const void* code, uint64_t size,
                                 const int32_t* template_flags, const int32_t* group_flags,
                                 const int32_t* pair_offsets, const int32_t* pair_entries,

@@ -421,21 +421,24 @@ def test_bit_sliced_barcode_kernels_equal_the_binary16_kernels_and_the_oracle(mo
     want, want_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
     bases, offsets = native.pack_reads(reads)
     got = {}
-    for off in (None, "1"):
-        if off:
-            monkeypatch.setenv("QCAT_HIP_NO_BITSLICE", off)
+    monkeypatch.setenv("QCAT_HIP_BITSLICE_MIN", "16384")     # (the path is for batches that fill the chip: force it here)
+    for variant in ("static letters", "letters from memory", "off"):
+        if variant == "letters from memory":
+            monkeypatch.setenv("QCAT_HIP_NO_BS_STATIC", "1")
+        elif variant == "off":
+            monkeypatch.setenv("QCAT_HIP_NO_BITSLICE", "1")
         cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
         ctx = native.NativeContext(0)
         lib = native.HipLibrary.get().lib
         native.HipLibrary.get().check(lib.qcat_ctx_set_timing(ctx.handle, 1))
-        got[off] = ctx.scan(native.NativeKit(d), bases, offsets, counts=cnt)
+        got[variant] = ctx.scan(native.NativeKit(d), bases, offsets, counts=cnt)
         names = (C.c_char_p * 16)()
         ms = (C.c_float * 16)()
         k = lib.qcat_ctx_last_timing(ctx.handle, names, ms, 16)
         ran = [names[i].decode() for i in range(k)]
-        assert ("k_barcode_bitslice" in ran) == (off is None), (off, ran)
-        bad = np.nonzero(got[off] != want)[0]
-        assert len(bad) == 0, (off, bad[:10], got[off][bad[:3]], want[bad[:3]])
+        assert ("k_barcode_bitslice" in ran) == (variant != "off"), (variant, ran)
+        bad = np.nonzero(got[variant] != want)[0]
+        assert len(bad) == 0, (variant, bad[:10], got[variant][bad[:3]], want[bad[:3]])
         assert np.array_equal(cnt, want_cnt)
 
 
