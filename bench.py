@@ -267,7 +267,7 @@ def main():
             up = nb.value if a.workload == "middle" else int(np.minimum(np.diff(ho).astype(np.int64), keep).sum())
             out["host_inclusive"] = {"value": round(a.reads / best, 1), "unit": "reads/s",
                                      "note": "qcat_scan_batch from pageable host memory (%.0f MB of reads), records identical to the "
-                                             "resident scan's: chunks of 256 k reads are compacted to their scanned windows on host "
+                                             "resident scan's: chunks of 256 k to 1 M reads are compacted to their scanned windows on host "
                                              "threads, uploaded and scanned as a three-stage pipeline; %.0f MB up, %.0f MB down per step"
                                              % (nb.value / 1e6, up / 1e6, a.reads * 24 / 1e6)}
             del hb, ho, hout

@@ -957,12 +957,14 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
         }
     }
     HostPipeline* p = c->pipe;
-    // chunks of 128 k .. 1 M reads (an eighth of the batch): big enough to fill the chip (1 000+ tiles of 128
+    // chunks of 256 k .. 1 M reads (a quarter of the batch): big enough to fill the chip (1 000+ tiles of 128
     // alignments), small enough that the first chunk's compaction and the last chunk's scan -- the only
     // stages nothing overlaps -- are a small part of the call
     const char* ce = getenv("QCAT_HIP_PIPELINE_CHUNK");
     // (heavier per-chunk launches lose less to the tails of the persistent barcode kernels: large batches take 1 M-read chunks)
-    const uint32_t chunk = ce ? (uint32_t)std::max(4096, atoi(ce)) : std::min<uint32_t>(1048576u, std::max<uint32_t>(131072u, n_reads / 8u));
+    // (a chunk costs ~0.3 ms of host time in launches and copies whatever its size: 1 M reads of a small kit run
+    // 166 M reads/s in four chunks, 137 M in eight, 97 M in sixteen)
+    const uint32_t chunk = ce ? (uint32_t)std::max(4096, atoi(ce)) : std::min<uint32_t>(1048576u, std::max<uint32_t>(262144u, n_reads / 4u));
     const uint32_t n_chunks = (n_reads + chunk - 1) / chunk;
     if ((size_t)n_reads > p->cap_results) {
         if (p->pin_results) (void)hipHostFree(p->pin_results);
@@ -1038,7 +1040,17 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
         p->pool->run(parts, [&](int part) {
             const uint32_t a = std::min<uint32_t>(nr, (uint32_t)part * per), b2 = std::min<uint32_t>(nr, a + per);
             uint64_t pos = part_total[part];
-            for (uint32_t r = a; r < b2; ++r) {
+            constexpr uint32_t AHEAD = 12;                           // reads: the windows are 150 B out of every ~700, each a cache
+            for (uint32_t r = a; r < b2; ++r) {                      // miss the hardware prefetcher does not see coming
+                if (r + AHEAD < b2) {
+                    const uint64_t px = offsets[r0 + r + AHEAD], py = offsets[r0 + r + AHEAD + 1];
+                    const uint8_t* ps = bases + px;
+                    __builtin_prefetch(ps, 0, 0); __builtin_prefetch(ps + 64, 0, 0); __builtin_prefetch(ps + 128, 0, 0);
+                    if (both && py - px > keep) {
+                        const uint8_t* pt = bases + py - n;
+                        __builtin_prefetch(pt, 0, 0); __builtin_prefetch(pt + 64, 0, 0); __builtin_prefetch(pt + 128, 0, 0);
+                    }
+                }
                 const uint64_t x = offsets[r0 + r];
                 const uint64_t len = offsets[r0 + r + 1] - x;
                 const uint8_t* src = bases + x;
