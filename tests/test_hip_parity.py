@@ -496,3 +496,50 @@ def test_one_kit_shared_by_concurrent_contexts():
         t.join()
     assert not errors, errors
     assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("letters", ["compiled in", "from memory"])
+def test_bit_sliced_shapes_of_custom_kits(letters, tmp_path, monkeypatch):
+    """The bit-sliced kernels cut a target into shared leading columns (0, 4, 8 or 11 of the longer context) and own
+    columns, and walk it backwards when the downstream context is the longer one.  The built-in kits only have 8 and
+    11 shared columns: custom kits with short flanks cover the other shapes, on the run-time generated static-letter
+    kernels and on the letters-from-memory kernels (both need the kit's generated binary16 chains for the tiles the
+    super-tiles leave over, so the kits are compiled first)."""
+    import custom_kits
+    import random
+    rng = random.Random(31)
+    folder = str(tmp_path)
+    # name: (upstream flank, downstream flank, barcode_context_length) -> shared columns / direction
+    shapes = {"P0": ("GGTGCTG", "TTAACCTTTCTGTTGG", 3), "P4F": ("GGTCA", "CAG", 11), "P4R": ("TG", "CAGCAC", 11),
+              "P8F": ("CGGTGCTGA", "TTAA", 11), "P8R": ("GCTG", "TTAACCTACT", 11), "P11R": ("GGTGCTG", "TTAACCTTTCTGTTGG", 11)}
+    for name, (up, dn, _) in shapes.items():
+        blen = 28 if name == "P0" else 24           # (a target needs 32 columns for the packed path: 3 + 28 + 3)
+        custom_kits.write_kit(folder, name, name, up + "N" * blen + dn, custom_kits.random_barcodes(rng, 20, length=blen))
+    monkeypatch.setenv("QCAT_HIP_BITSLICE_MIN", "2048")
+    if letters == "from memory":
+        monkeypatch.setenv("QCAT_HIP_NO_BS_STATIC", "1")
+    lib = native.HipLibrary.get().lib
+    for name in shapes:
+        det = scanner.factory(kit=name, kit_folder=folder)
+        cfg = config.qcatConfig()
+        cfg.barcode_context_length = shapes[name][2]
+        d = det.descriptor(qcat_config=cfg, ends=native.ENDS_5P)
+        kit = native.NativeKit(d, jit=True)
+        info = kit.describe()
+        assert info["bitslice_groups"] == 0x10001 and info["n_static_groups"] == 1, (name, info)
+        reads = synth.synth_batch(12000, 77, det.layouts, 0, -1, error_rate=0.08)
+        reads[5], reads[6] = "", "ACGT" * 50
+        want, want_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
+        bases, offsets = native.pack_reads(reads)
+        cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+        ctx = native.NativeContext(0)
+        native.HipLibrary.get().check(lib.qcat_ctx_set_timing(ctx.handle, 1))
+        got = ctx.scan(kit, bases, offsets, counts=cnt)
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        ran = [names[i].decode() for i in range(lib.qcat_ctx_last_timing(ctx.handle, names, ms, 16))]
+        assert "k_barcode_bitslice" in ran, (name, ran)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (name, bad[:10], got[bad[:3]], want[bad[:3]])
+        assert np.array_equal(cnt, want_cnt)
