@@ -965,7 +965,19 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
     // (a chunk costs ~0.3 ms of host time in launches and copies whatever its size: 1 M reads of a small kit run
     // 166 M reads/s in four chunks, 137 M in eight, 97 M in sixteen)
     const uint32_t chunk = ce ? (uint32_t)std::max(4096, atoi(ce)) : std::min<uint32_t>(1048576u, std::max<uint32_t>(262144u, n_reads / 4u));
-    const uint32_t n_chunks = (n_reads + chunk - 1) / chunk;
+    // chunk boundaries: the first and the last chunk are a third of the others -- nothing overlaps the first chunk's
+    // compaction and the last chunk's upload + scan + download
+    std::vector<uint32_t> cuts;
+    cuts.push_back(0);
+    if (!ce && n_reads > 2 * chunk) {
+        const uint32_t edge = chunk / 3, mid = n_reads - 2 * edge, m = (mid + chunk - 1) / chunk;
+        for (uint32_t q = 0; q <= m; ++q) cuts.push_back(edge + (uint32_t)((uint64_t)mid * q / m));    // equal middle chunks
+        cuts.push_back(n_reads);
+    } else {
+        for (uint32_t pos = chunk; pos < n_reads; pos += chunk) cuts.push_back(pos);
+        cuts.push_back(n_reads);
+    }
+    const uint32_t n_chunks = (uint32_t)cuts.size() - 1;
     if ((size_t)n_reads > p->cap_results) {
         if (p->pin_results) (void)hipHostFree(p->pin_results);
         p->pin_results = nullptr; p->cap_results = 0;
@@ -1007,7 +1019,7 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
     for (uint32_t ci = 0; ci < n_chunks && !rc; ++ci) {
         PipeStage& st = p->st[ci & 1];
         double t0 = now();
-        const uint32_t r0 = ci * chunk, nr = std::min(chunk, n_reads - r0);
+        const uint32_t r0 = cuts[ci], nr = cuts[ci + 1] - r0;
         if (ci >= 2) HIPCHK(hipEventSynchronize(st.copied));          // this slot's pinned staging has been read
         t_wait += now() - t0; t0 = now();
         // offsets + real lengths of the compacted chunk: per-part sums in parallel, a serial scan over the parts,
