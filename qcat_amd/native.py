@@ -7,6 +7,7 @@ there is no CPU fallback on the product path.
 """
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -347,6 +348,8 @@ class NativeKit(object):
         return {name: int(getattr(info, name)) for name, _ in KitInfo._fields_ }
 
     def __del__(self):
+        if sys.is_finalizing():
+            return                                   # interpreter exit: the HIP runtime may be gone already, the process's memory goes with it
         th = getattr(self, "jit_thread", None)
         if th is not None and th.is_alive():
             return                                   # the compile thread still owns handles: leak rather than race
@@ -405,6 +408,8 @@ class NativeComm(object):
             self.handle = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -423,7 +428,7 @@ class NativeContext(object):
 
     def __del__(self):
         h = getattr(self, "handle", None)
-        if h:
+        if h and not sys.is_finalizing():            # (at interpreter exit the HIP runtime may be gone already)
             try:
                 self.hip.lib.qcat_ctx_destroy(h)
             except Exception:
