@@ -1,3 +1,6 @@
+#!/bin/bash
+# Quick A/B loop for the bit-sliced barcode kernels on the GPU box: the parity tests that force the path, then one
+# bench line per workload with static letters and (config 3 / 2) with the letters from memory.
 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "bit_sliced or zero or summary" 2>&1 | tail -3
 for w in config3 config2 dual dual96; do python bench.py --workload $w --steps 5 --warmup 2 --no-host-inclusive 2>gpurun_out/bs_$w.err | tail -1 > gpurun_out/bs_$w.json; python -c "
 import json
