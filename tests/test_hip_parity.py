@@ -422,8 +422,11 @@ def test_bit_sliced_barcode_kernels_equal_the_binary16_kernels_and_the_oracle(mo
     bases, offsets = native.pack_reads(reads)
     got = {}
     monkeypatch.setenv("QCAT_HIP_BITSLICE_MIN", "16384")     # (the path is for batches that fill the chip: force it here)
-    for variant in ("static letters", "letters from memory", "off"):
-        if variant == "letters from memory":
+    for variant in ("static letters", "side streams", "letters from memory", "off"):
+        if variant == "side streams":                            # (the arrangement of big batches: one stream per target family)
+            monkeypatch.setenv("QCAT_HIP_BS_SIDE", "1")
+        elif variant == "letters from memory":
+            monkeypatch.delenv("QCAT_HIP_BS_SIDE")
             monkeypatch.setenv("QCAT_HIP_NO_BS_STATIC", "1")
         elif variant == "off":
             monkeypatch.setenv("QCAT_HIP_NO_BITSLICE", "1")
