@@ -513,7 +513,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     }, (int16_t*)nullptr, 0u, [](const char*) {});
     if (!rc) rc = jit_take_error();
     if (rc) return set_err(rc, packed_last_error());
-    hipLaunchKernelGGL(k_mid_finalize, dim3((n + 255) / 256), dim3(256), 0, st, kp.kit, c->mid_recs, c->mid_slot, n, c->results);
+    hipLaunchKernelGGL(k_mid_finalize, dim3((n + 255) / 256), dim3(256), 0, st, kp.kit, c->mid_recs, c->mid_slot, n, c->results, c->mid_generic);
     HIPCHK(hipGetLastError());
     return 0;
 }
