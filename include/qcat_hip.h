@@ -69,7 +69,8 @@ enum { QCAT_ENDS_5P = 1,          /* scan() on the 5' window only (BASELINE conf
        QCAT_ENDS_BOTH = 3 };      /* detect_barcode(): 5' + 3' (qcat/scanner_base.py:521-604) */
 
 /* One barcode set of one template (qcat/layout.py:176-189 get_barcode_set).
- * `sequences` holds n * barcode_len ASCII characters, barcode b at sequences + b*barcode_len.
+ * `sequences` holds n * barcode_len ASCII characters (NUL-terminated: a shorter string is rejected with
+ * QCAT_ERR_ARG), barcode b at sequences + b*barcode_len -- every barcode of a set has the same length.
  * `ids[b]` is a dense integer standing for Barcode.id -- only equality is ever used
  * (qcat/scanner_base.py:589); the host maps YAML ids to ints. */
 typedef struct qcat_barcode_set_desc {
@@ -170,6 +171,9 @@ typedef struct qcat_batch qcat_batch;  /* reads resident in device memory       
 const char* qcat_last_error(void);
 int  qcat_abi_version(void);
 int  qcat_device_count(void);
+/* NUMA node of the device's PCI function (from sysfs), -1 when unknown.  No reference counterpart (the reference is
+ * single-process): the rank launcher uses it to keep a rank's host threads beside its GPU. */
+int  qcat_device_numa_node(int device);
 
 /* replaces: BarcodeScanner.__init__ kit selection + qcatConfig (scanner_base.py:415-447). */
 int  qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out);

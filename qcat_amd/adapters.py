@@ -93,20 +93,13 @@ def _bundle_entries():
 
 def get_barcodes_from_fastq(reads_fa):
     """Barcode list from a FASTA file, ids 1.. in file order (``qcat/adapters.py:108-118``)."""
-    barcodes, title, seq = [], None, []
-
-    def flush():
-        if title is not None:
-            barcodes.append(read_barcode({"name": title, "id": len(barcodes) + 1, "sequence": "".join(seq)}))
+    # the same reading rules as SimpleFastaParser, which the reference uses here: interior blanks and
+    # carriage returns of a sequence are dropped (one helper for the driver and this loader)
+    from .cli import _fasta_records
+    barcodes = []
     with open(reads_fa) as fh:
-        for line in fh:
-            line = line.rstrip("\n")
-            if line.startswith(">"):
-                flush()
-                title, seq = line[1:].rstrip(), []
-            elif title is not None:
-                seq.append(line.strip())
-    flush()
+        for title, seq in _fasta_records(fh):
+            barcodes.append(read_barcode({"name": title, "id": len(barcodes) + 1, "sequence": seq}))
     if len(barcodes) <= 0:
         logging.error("Couldn't find barcodes in {}".format(reads_fa))
     return barcodes

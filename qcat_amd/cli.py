@@ -132,7 +132,7 @@ def _fastq_records_general(lines):
         if second and second != title:
             raise ValueError("Sequence and quality captions differ.")
         seq = "".join(seq_parts)
-        if " " in seq:
+        if " " in seq or "\t" in seq:                          # (FastqGeneralIterator rejects blanks and tabs)
             raise ValueError("Whitespace is not allowed in the sequence.")
         qual = next(lines, "").rstrip()
         line = next(lines, "")
@@ -150,7 +150,7 @@ def _fastq_records(handle):
     lines = iter(handle)
     for head, seq, plus, qual in itertools.zip_longest(lines, lines, lines, lines, fillvalue=""):
         seq_s, qual_s = seq.rstrip(), qual.rstrip()
-        if head[:1] == "@" and plus[:1] == "+" and len(qual_s) == len(seq_s) and seq_s and " " not in seq_s \
+        if head[:1] == "@" and plus[:1] == "+" and len(qual_s) == len(seq_s) and seq_s and " " not in seq_s and "\t" not in seq_s \
                 and (len(plus) <= 2 or plus[1:].rstrip() in ("", head[1:].rstrip())):
             yield head[1:].rstrip(), seq_s, qual_s
             continue

@@ -8,7 +8,10 @@
 // (see DESIGN.md for the data layout and the roofline of each kernel).
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -53,6 +56,34 @@ extern "C" int qcat_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// NUMA node of a device's PCI function (sysfs), -1 when unknown: the rank launcher (qcat_amd/parallel.py) keeps a
+// rank's host threads -- the compaction pool of host_pipeline.inc -- on the node its GPU hangs off
+extern "C" int qcat_device_numa_node(int device) {
+    char bdf[64] = {0};
+    if (device < 0 || device >= qcat_device_count()) return -1;
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) return -1;
+    for (char* q = bdf; *q; ++q) *q = (char)tolower((unsigned char)*q);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/numa_node";
+    FILE* fh = fopen(path.c_str(), "r");
+    if (!fh) return -1;
+    int node = -1;
+    if (fscanf(fh, "%d", &node) != 1) node = -1;
+    fclose(fh);
+    return node;
+}
+
+// host threads a context may use for compaction / parsing: QCAT_HOST_THREADS (the rank launcher sets it to this
+// rank's share of the container's CPU quota), else the CPUs of the affinity mask, at most 16
+static inline unsigned host_threads() {
+    const char* e = getenv("QCAT_HOST_THREADS");
+    if (e && atoi(e) > 0) return (unsigned)std::min(atoi(e), 64);
+    unsigned n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
+    if (!n) n = std::max(1u, std::thread::hardware_concurrency());
+    return std::min(n, 16u);
 }
 
 // temporary device allocation released on every exit path
@@ -754,8 +785,7 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
         c->cap_pin_bases = total + 1;
     }
     {
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const unsigned nthreads = std::min<unsigned>(std::min(hw, 16u), std::max<uint32_t>(1u, n_reads / 16384u));
+        const unsigned nthreads = std::min<unsigned>(host_threads(), std::max<uint32_t>(1u, n_reads / 16384u));
         auto work = [&](uint32_t r0, uint32_t r1) {
             for (uint32_t r = r0; r < r1; ++r) {
                 const uint8_t* src = bases + offsets[r];
@@ -943,8 +973,7 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
     const uint64_t keep = both ? 2 * n : n;
     if (!c->pipe) {
         c->pipe = new HostPipeline();
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        c->pipe->pool = new HostPool(std::min(hw, 16u) - 1);
+        c->pipe->pool = new HostPool(host_threads() - 1);
         // the copy stream gets the highest priority: the runtime multiplexes streams of one priority onto a few
         // hardware queues, and a copy queued behind a 20 ms persistent barcode kernel of a side stream would
         // not start before that kernel ends (measured: no copy/compute overlap at all on a default stream)

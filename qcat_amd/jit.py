@@ -280,7 +280,36 @@ def _prelude_digest():
             with open(os.path.join(CSRC, name), "rb") as fh:
                 h.update(name.encode())
                 h.update(fh.read())
+    # kit.h includes the ABI header (struct layouts, enums, QCAT_MAX_*): part of every code object's layout
+    abi = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "qcat_hip.h")
+    try:
+        with open(abi, "rb") as fh:
+            h.update(b"qcat_hip.h")
+            h.update(fh.read())
+    except OSError:
+        pass
     return h.hexdigest()
+
+
+_toolchain = {}
+
+
+def _toolchain_version(how):
+    """version string of the compiler a code object comes from (part of the cache key)"""
+    if how not in _toolchain:
+        ver = ""
+        try:
+            if how == "hiprtc":
+                major, minor = C.c_int(0), C.c_int(0)
+                if hiprtc().hiprtcVersion(C.byref(major), C.byref(minor)) == 0:
+                    ver = "hiprtc-%d.%d" % (major.value, minor.value)
+            else:
+                out = subprocess.run([hipcc_path(), "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                ver = hashlib.sha1(out.stdout).hexdigest()
+        except (OSError, AttributeError, TypeError):
+            ver = ""
+        _toolchain[how] = ver
+    return _toolchain[how]
 
 
 def _compile_hiprtc(source):
@@ -332,8 +361,9 @@ def cache_dir():
 
 
 def _cache_load(path):
-    """the cached code object, or None when it is absent or does not match its recorded SHA-256 (a
-    truncated / tampered file must never reach hipModuleLoadData)"""
+    """the cached code object, or None when it is absent or does not match its recorded SHA-256.  The digest sits
+    beside the blob in the same user-writable directory, so this catches truncation and corruption (a half-written
+    file must never reach hipModuleLoadData), not tampering by someone who can write there."""
     try:
         with open(path, "rb") as fh:
             blob = fh.read()
@@ -364,7 +394,10 @@ def compile_source(source):
     if how is None:
         raise RuntimeError("qcat_amd.jit: neither libhiprtc nor hipcc found (QCAT_AMD_HIPRTC / HIPCC); "
                            "cannot generate kernels for this kit")
-    key = hashlib.sha1((source + _prelude_digest() + ARCH).encode()).hexdigest()
+    # the key covers everything the code object's layout depends on: the generated source, the kernel headers AND the
+    # ABI header they include (struct / enum / MAX_* constants), the compile route (hipcc and hipRTC use different
+    # preludes) and the toolchain version
+    key = hashlib.sha1((source + _prelude_digest() + ARCH + how + _toolchain_version(how)).encode()).hexdigest()
     path = os.path.join(cache_dir(), key + ".hsaco")
     blob = _cache_load(path)
     if blob is not None:

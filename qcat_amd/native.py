@@ -125,6 +125,15 @@ class KitDescriptor(object):
                     sd.n = 0
                     sd.barcode_len = 0
                     continue
+                # the native layer takes a set as n rows of ONE length (qcat_barcode_set_desc); the reference aligns
+                # every barcode with its own length (scanner_base.py:112-117), so lists of unequal length -- only a
+                # user FASTA in simple mode can hold them -- are refused here instead of being sliced wrongly
+                lens = set(len(b.sequence) for b in bset)
+                if len(lens) != 1 or 0 in lens:
+                    raise RuntimeError("barcode set %d of %s holds barcodes of different lengths (%s): the device "
+                                       "path needs one length per set"
+                                       % (i + 1, getattr(lay, "kit", "the barcode list"),
+                                          ", ".join(str(n) for n in sorted(lens))))
                 blob = "".join(b.sequence for b in bset).encode("latin-1", "replace")
                 ids = (C.c_int32 * len(bset))()
                 for j, b in enumerate(bset):
@@ -233,6 +242,7 @@ class HipLibrary(object):
             "qcat_last_error": (C.c_char_p, []),
             "qcat_abi_version": (C.c_int, []),
             "qcat_device_count": (C.c_int, []),
+            "qcat_device_numa_node": (C.c_int, [C.c_int]),
             "qcat_kit_create": (C.c_int, [C.POINTER(KitDesc), C.POINTER(vp)]),
             "qcat_kit_destroy": (None, [vp]),
             "qcat_kit_count_buckets": (C.c_int, [vp]),

@@ -8,18 +8,31 @@ This module is the host side of that: the shard arithmetic, the rendezvous that 
 128-byte RCCL unique id from rank 0 to the other ranks (a TCP socket on the node -- no PyTorch, no
 MPI), and a launcher that starts one process per GPU.  Nothing here touches the kernels.
 """
+import hashlib
 import os
 import socket
 import struct
 import subprocess
 import sys
 import time
+import uuid
 
 from . import native
 
-_MAGIC_REQ = b"QCATRDZV1"
-_MAGIC_REP = b"QCATID001"
+_MAGIC_REQ = b"QCATRDZV2"
+_MAGIC_REP = b"QCATID002"
 _N_CANDIDATE_PORTS = 16
+_NONCE_BYTES = 8
+
+
+def job_nonce(environ=None):
+    """Eight bytes that tell this job's rendezvous from another job's on the same node: derived from
+    QCAT_RDZV_NONCE (set by :func:`launch`) or, under a foreign launcher, from its run id and MASTER_PORT
+    (every rank of one job sees the same values, two jobs of one node cannot share a MASTER_PORT)."""
+    env = os.environ if environ is None else environ
+    src = env.get("QCAT_RDZV_NONCE") or "%s|%s|%s" % (env.get("TORCHELASTIC_RUN_ID", ""), env.get("MASTER_ADDR", ""),
+                                                       env.get("MASTER_PORT", "29500"))
+    return hashlib.sha256(src.encode("utf-8", "replace")).digest()[:_NONCE_BYTES]
 
 
 def shard_range(n_items, rank, world_size):
@@ -67,13 +80,15 @@ def _recv_exact(conn, n):
 
 def exchange_id(rank, world_size, make_id, environ=None, timeout=300.0):
     """Rank 0 calls ``make_id()`` (-> bytes) and serves the result to the other ``world_size - 1``
-    ranks over TCP on MASTER_ADDR; every rank returns the same bytes.  The request carries the world
-    size, so a stale server of another job on a neighbouring port is told apart and skipped."""
+    ranks over TCP on MASTER_ADDR; every rank returns the same bytes.  Request and reply carry the job's
+    nonce (:func:`job_nonce`) and the world size, so a server or a rank of another job on a neighbouring
+    port is told apart and skipped, and a rank is counted once."""
     env = os.environ if environ is None else environ
     if world_size == 1:
         return make_id()
     addr = env.get("MASTER_ADDR", "127.0.0.1")
     ports = _candidate_ports(env)
+    nonce = job_nonce(env)
     deadline = time.time() + timeout
     if rank == 0:
         srv = None
@@ -101,28 +116,31 @@ def exchange_id(rank, world_size, make_id, environ=None, timeout=300.0):
                 with conn:
                     conn.settimeout(10.0)
                     try:
-                        req = _recv_exact(conn, len(_MAGIC_REQ) + 8)
-                        w, r = struct.unpack("<ii", req[len(_MAGIC_REQ):])
-                        if req[:len(_MAGIC_REQ)] != _MAGIC_REQ or w != world_size or not (0 < r < world_size):
+                        req = _recv_exact(conn, len(_MAGIC_REQ) + _NONCE_BYTES + 8)
+                        w, r = struct.unpack("<ii", req[len(_MAGIC_REQ) + _NONCE_BYTES:])
+                        # another job's rank (wrong nonce), a malformed request or a rank that was already
+                        # served gets no id and is not counted
+                        if (req[:len(_MAGIC_REQ)] != _MAGIC_REQ or req[len(_MAGIC_REQ):len(_MAGIC_REQ) + _NONCE_BYTES] != nonce
+                                or w != world_size or not (0 < r < world_size) or r in served):
                             continue
-                        conn.sendall(_MAGIC_REP + struct.pack("<i", len(payload)) + payload)
+                        conn.sendall(_MAGIC_REP + nonce + struct.pack("<i", len(payload)) + payload)
                         served.add(r)
                     except (OSError, ConnectionError, struct.error):
                         continue
         finally:
             srv.close()
         return payload
-    req = _MAGIC_REQ + struct.pack("<ii", world_size, rank)
+    req = _MAGIC_REQ + nonce + struct.pack("<ii", world_size, rank)
     while time.time() < deadline:
         for p in ports:
             try:
                 with socket.create_connection((addr, p), timeout=2.0) as conn:
                     conn.settimeout(10.0)
                     conn.sendall(req)
-                    head = _recv_exact(conn, len(_MAGIC_REP) + 4)
-                    if head[:len(_MAGIC_REP)] != _MAGIC_REP:
-                        continue
-                    (n,) = struct.unpack("<i", head[len(_MAGIC_REP):])
+                    head = _recv_exact(conn, len(_MAGIC_REP) + _NONCE_BYTES + 4)
+                    if head[:len(_MAGIC_REP)] != _MAGIC_REP or head[len(_MAGIC_REP):len(_MAGIC_REP) + _NONCE_BYTES] != nonce:
+                        continue                             # some other job's server: try the next port
+                    (n,) = struct.unpack("<i", head[len(_MAGIC_REP) + _NONCE_BYTES:])
                     return _recv_exact(conn, n)
             except (OSError, ConnectionError, struct.error):
                 continue
@@ -149,20 +167,108 @@ def init_comm(ctx, rank=None, world_size=None, environ=None):
         os.close(saved)
 
 
+def _cgroup_cpu_quota():
+    """CPUs the container may use according to its cgroup quota (None: unlimited)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2
+            q, per = fh.read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+    except (IOError, OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+            q, per = float(fq.read()), float(fp.read())
+            return q / per if q > 0 else None
+    except (IOError, OSError, ValueError):
+        return None
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def rank_cpu_plan(n_ranks, numa_nodes=None, affinity=None, quota=None, node_cpus=None):
+    """Host-side placement of the ranks of one node: (cpu set, host threads) per rank.
+
+    A rank's host work is the window-compaction pool of ``qcat_scan_batch`` (up to 16 threads): left alone, 8 ranks
+    start 8 x 16 threads on whatever CPUs the scheduler picks -- far from their GPUs and, under the container's CPU
+    quota, 8x oversubscribed.  Rank r gets the CPUs of its GPU's NUMA node (``numa_nodes[r]``, -1 / None: unknown ->
+    the whole affinity mask), split evenly among the ranks that share the node, and
+    ``max(1, usable CPUs // n_ranks)`` host threads where usable = min(affinity mask, cgroup quota)."""
+    if affinity is None:
+        try:
+            affinity = set(os.sched_getaffinity(0))
+        except AttributeError:
+            affinity = set(range(os.cpu_count() or 1))
+    affinity = set(affinity)
+    if quota is None:
+        quota = _cgroup_cpu_quota()
+    usable = len(affinity) if not quota else max(1, min(len(affinity), int(quota + 0.5)))
+    threads = max(1, usable // n_ranks)
+    numa_nodes = list(numa_nodes) if numa_nodes is not None else [-1] * n_ranks
+
+    def cpus_of(node):
+        if node is None or node < 0:
+            return None
+        if node_cpus is not None:
+            return set(node_cpus.get(node, ())) & affinity or None
+        try:
+            with open("/sys/devices/system/node/node%d/cpulist" % node) as fh:
+                return (_parse_cpulist(fh.read()) & affinity) or None
+        except (IOError, OSError, ValueError):
+            return None
+
+    plan = []
+    for r in range(n_ranks):
+        local = cpus_of(numa_nodes[r])
+        if local is None:
+            plan.append((sorted(affinity), threads))
+            continue
+        mates = [q for q in range(n_ranks) if numa_nodes[q] == numa_nodes[r]]      # ranks sharing the node
+        share = sorted(local)
+        k, m = mates.index(r), len(mates)
+        mine = share[k * len(share) // m:(k + 1) * len(share) // m] or share
+        plan.append((mine, threads))
+    return plan
+
+
 def launch(n_ranks, argv, environ=None):
     """Start ``n_ranks`` copies of ``python argv...`` on this node, rank r bound to GPU r through
-    RANK / LOCAL_RANK / WORLD_SIZE (the variables ``torch.distributed.run`` sets), and wait for all
-    of them.  Returns the largest exit status; a failing rank takes the others down."""
+    RANK / LOCAL_RANK / WORLD_SIZE (the variables ``torch.distributed.run`` sets), to the CPUs of that
+    GPU's NUMA node and to its share of the container's CPU quota (:func:`rank_cpu_plan`;
+    QCAT_HOST_THREADS tells the native library), and wait for all of them.  Returns the largest exit
+    status; a failing rank takes the others down."""
     env = dict(os.environ if environ is None else environ)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env["QCAT_RDZV_PORT"] = str(free_port())
+    env["QCAT_RDZV_NONCE"] = uuid.uuid4().hex             # this job's rendezvous only (exchange_id)
     env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n_ranks)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        lib = native.HipLibrary.get().lib
+        nodes = [lib.qcat_device_numa_node(r) for r in range(n_ranks)]
+    except (RuntimeError, OSError, AttributeError):
+        nodes = None
+    plan = rank_cpu_plan(n_ranks, nodes)
     procs = []
     for r in range(n_ranks):
         e = dict(env)
         e["RANK"] = e["LOCAL_RANK"] = str(r)
-        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
+        cpus, threads = plan[r]
+        e.setdefault("QCAT_HOST_THREADS", str(threads))
+
+        def bind(cpus=cpus):
+            try:
+                os.sched_setaffinity(0, cpus)
+            except (AttributeError, OSError, ValueError):
+                pass
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e, preexec_fn=bind))
     worst = 0
     alive = list(procs)
     while alive:

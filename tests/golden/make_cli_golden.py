@@ -52,16 +52,36 @@ def main():
     ]
     file_kits = {"nbd103.fastq": "NBD104/NBD114", "pbk004.fastq": "PBK004/LWB001",
                  "rab204.fastq": "RAB204/RAB214", "rbk004.fastq": "RBK004"}
-    for fname in sorted(file_kits):
-        for v in variants:
-            kit = v["kit"] if v["kit"] else file_kits[fname]
+    # BASELINE config 1 (ii): the README's 193-read LWB001 example as a generated file (tests/synth.py:
+    # config1_fastq; not committed -- the test regenerates it from the seed), through the README's own command shapes
+    only_config1 = "--only-config1" in sys.argv
+    sys.path.insert(0, os.path.dirname(HERE))
+    import synth  # noqa: E402
+    import qcat.adapters as ref_adapters
+    lwb = [l for l in ref_adapters.populate_adapter_layouts() if l.kit == synth.CONFIG1["kit"]]   # loader order = sorted file names (3p, 5p)
+    tmpd = tempfile.mkdtemp(prefix="qcat_cfg1_")
+    cfg1 = os.path.join(tmpd, "config1_lwb001_193.fastq")
+    with open(cfg1, "w") as fh:
+        fh.write(synth.config1_fastq(lwb))
+    file_kits_all = dict(file_kits)
+    jobs = [] if only_config1 else [(os.path.join(data, f), f, v) for f in sorted(file_kits) for v in variants]
+    jobs += [(cfg1, "config1_lwb001_193.fastq", v) for v in variants if v["tag"] in ("tsv-auto-batch", "dir-auto-trim")]
+    jobs.append((cfg1, "config1_lwb001_193.fastq",
+                 {"tag": "dir-auto-readme", "kit": "auto", "mode": "epi2me", "nobatch": False, "tsv": False, "trim": False, "min_len": 100, "dir": True}))
+    file_kits_all["config1_lwb001_193.fastq"] = synth.CONFIG1["kit"]
+    if only_config1:
+        with open(os.path.join(HERE, "cli_golden.json")) as fh:
+            runs = [r for r in json.load(fh)["runs"] if not r["file"].startswith("config1_")]
+    for path, fname, v in jobs:
+        if True:                                           # (indentation kept from the per-file loop)
+            kit = v["kit"] if v["kit"] else file_kits_all[fname]
             tmp = tempfile.mkdtemp(prefix="qcat_cli_")
             outdir = os.path.join(tmp, "bc") if v["dir"] else None
             outfile = os.path.join(tmp, "out.fastq")
             cap.lines = []
             buf = io.StringIO()
             with contextlib.redirect_stdout(buf):
-                ref_cli.qcat_cli(reads_fq=os.path.join(data, fname), kit=kit, mode=v["mode"], nobatch=v["nobatch"],
+                ref_cli.qcat_cli(reads_fq=path, kit=kit, mode=v["mode"], nobatch=v["nobatch"],
                                  out=outdir, min_qual=None, tsv=v["tsv"], output=None if v["dir"] else outfile,
                                  threads=1, trim=v["trim"], adapter_yaml=None, quiet=False, filter_barcodes=False,
                                  middle_adapter=False, min_read_length=v["min_len"], qcat_config=cfg)

@@ -79,7 +79,9 @@ def _mutate(rng, seq, thr, out):
 
 
 def synth_read(index, seed, layouts, tpl_5p, tpl_3p, error_rate=0.0, no_adapter_fraction=0.05,
-               insert_len=600, lead_min=5, lead_max=40):
+               insert_len=600, lead_min=5, lead_max=40, force_barcode=None, force_bare=None):
+    """``force_barcode`` / ``force_bare`` override the drawn barcode / adapter-free flag without changing the
+    random stream (config 1's file: a fixed barcode and a fixed number of adapter-free reads)."""
     rng = SplitMix64(seed, index)
     thr_err = rate_threshold(error_rate)
     thr_none = rate_threshold(no_adapter_fraction)
@@ -89,6 +91,10 @@ def synth_read(index, seed, layouts, tpl_5p, tpl_3p, error_rate=0.0, no_adapter_
     tail = lead_min + rng.below(span)
     b = rng.below(1 << 16)
     b2 = rng.below(1 << 16)
+    if force_barcode is not None:
+        b = force_barcode
+    if force_bare is not None:
+        bare = force_bare
     out = []
     for _ in range(lead):
         out.append(_BASES[rng.below(4)])
@@ -105,3 +111,20 @@ def synth_read(index, seed, layouts, tpl_5p, tpl_3p, error_rate=0.0, no_adapter_
 
 def synth_batch(n, seed, layouts, tpl_5p, tpl_3p, first=0, **kw):
     return [synth_read(first + i, seed, layouts, tpl_5p, tpl_3p, **kw) for i in range(n)]
+
+
+CONFIG1 = {"seed": 20260928, "n_barcoded": 191, "n_bare": 2, "error_rate": 0.08, "insert_len": 300,
+           "kit": "PBK004/LWB001", "bare_at": (57, 140)}
+
+
+def config1_fastq(layouts):
+    """BASELINE config 1 (ii): the README's 193-read example as a generated FASTQ -- 191 reads of kit
+    PBK004/LWB001 carrying ``barcode01`` at both ends (8 % errors) and 2 adapter-free reads.  ``layouts`` = the kit's
+    templates in sorted order (3p, 5p).  Returns the file's text; names read000..read192, constant qualities."""
+    c = CONFIG1
+    lines = []
+    for i in range(c["n_barcoded"] + c["n_bare"]):
+        seq = synth_read(i, c["seed"], layouts, 1, 0, error_rate=c["error_rate"], insert_len=c["insert_len"],
+                         force_barcode=0, force_bare=(i in c["bare_at"]))
+        lines += ["@read%03d runid=config1 ch=%d" % (i, 1 + i % 512), seq, "+", "I" * len(seq)]
+    return "\n".join(lines) + "\n"

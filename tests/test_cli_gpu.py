@@ -45,8 +45,16 @@ def test_cli_matches_reference_driver(idx, tmp_path):
     root.addHandler(cap)
     root.setLevel(logging.INFO)
     buf = io.StringIO()
+    reads_fq = os.path.join(helpers.GOLDEN, "data", run["file"])
+    if run["file"].startswith("config1_"):
+        # BASELINE config 1: the README's 193-read LWB001 example, regenerated from its seed (tests/synth.py)
+        import synth
+        from qcat_amd import scanner
+        reads_fq = str(tmp_path / run["file"])
+        with open(reads_fq, "w") as fh:
+            fh.write(synth.config1_fastq(scanner.factory(kit=synth.CONFIG1["kit"]).layouts))
     try:
-        cli.qcat_cli(reads_fq=os.path.join(helpers.GOLDEN, "data", run["file"]), kit=run["kit"], mode=v["mode"],
+        cli.qcat_cli(reads_fq=reads_fq, kit=run["kit"], mode=v["mode"],
                      nobatch=v["nobatch"], out=outdir, min_qual=None, tsv=v["tsv"],
                      output=None if v["dir"] else outfile, threads=1, trim=v["trim"], adapter_yaml=None,
                      quiet=False, filter_barcodes=False, middle_adapter=False, min_read_length=v["min_len"],
@@ -63,3 +71,16 @@ def test_cli_matches_reference_driver(idx, tmp_path):
     elif os.path.exists(outfile):
         files["out.fastq"] = _sha(outfile)
     assert files == run["files"]
+
+
+def test_config1_readme_summary_shape():
+    """Config 1 (ii): the summary of the 193-read LWB001 file has the shape of the README's example
+    (README.md:119-128 of the reference): one kit, one barcode, the adapter-free reads under `none`."""
+    run = [r for r in RUNS if r["file"].startswith("config1_") and r["variant"]["tag"] == "dir-auto-readme"][0]
+    log = run["log"]
+    assert log[0].startswith("Adapters detected in ") and log[0].endswith(" of 193 reads")
+    kits = [l.split()[0] for l in log[1:log.index([x for x in log if x.startswith("Barcodes detected")][0])]]
+    assert set(kits) <= {"PBK004/LWB001", "none"}
+    bars = [l.split()[0] for l in log[log.index([x for x in log if x.startswith("Barcodes detected")][0]) + 1:] if l.split()]
+    assert set(b for b in bars if b.startswith("barcode")) == {"barcode01"}
+    assert sorted(run["files"]) == ["barcode01.fastq", "none.fastq"]

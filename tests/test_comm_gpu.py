@@ -129,10 +129,28 @@ def test_bench_under_a_launcher_environment_with_one_rank():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(parallel.free_port()))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--reads", "100000", "--no-cpu-baseline", "--no-host-inclusive"],
+                        "--reads", "100000", "--cpu-seconds", "1"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["counts_total"] == 100000
     assert line["count_allreduce"].startswith("rccl") and "count_allreduce_ms" in line
     assert "config3" in line["config"]["workload"]
+    # a line printed under a launcher carries everything a single-process line does (the N > 1 lines of the
+    # scaling run are printed by this code path)
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] <= 1
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    assert line["parity"]["mismatches_vs_oracle"] == 0 and line["host_inclusive"]["value"] > 0
+    assert_no_fraction_above_one(line)
+
+
+def assert_no_fraction_above_one(obj, path="line"):
+    """every `frac` / `*_util*` field of the JSON line is a fraction of a hardware limit: never above 1"""
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if isinstance(v, (int, float)) and (k == "frac" or "util" in k or k.startswith("frac_")):
+                assert 0 <= v <= 1.0, "%s.%s = %r" % (path, k, v)
+            assert_no_fraction_above_one(v, path + "." + k)
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            assert_no_fraction_above_one(v, "%s[%d]" % (path, i))

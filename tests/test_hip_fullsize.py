@@ -89,8 +89,41 @@ def dual_histogram_from_records(desc, layouts, recs):
 
 def check_sample_against_oracle(r, recs, k, rng):
     idx = np.sort(rng.choice(r.n, size=k, replace=False))
-    want = oracle_lib.scan(r.desc, r.host_reads(idx), threads=8)
+    want = oracle_lib.scan(r.desc, r.host_reads(idx), threads=16)
     assert recs[idx].tobytes() == want.tobytes()
+
+
+def check_all_records_across_device_paths(r, recs, cnt, monkeypatch, n_generic=200000):
+    """Full-coverage self-check at size: the default path (bit-sliced barcode kernels + whatever adapter kernels the
+    batch takes) against two INDEPENDENT device formulations of the same scan -- every record of the batch with the
+    bit-sliced kernels switched off (packed binary16 DP: another algorithm, another data layout), and the first
+    `n_generic` reads on the general int32 kernel (one thread per read end, affine DP in LDS).  The oracle pins a
+    sample; this pins every read of the batch to a second and third implementation."""
+    monkeypatch.setenv("QCAT_HIP_NO_BITSLICE", "1")
+    monkeypatch.setenv("QCAT_HIP_NO_ADAPTER_BITSLICE", "1")
+    recs_b16, cnt_b16 = r.scan()
+    monkeypatch.delenv("QCAT_HIP_NO_BITSLICE")
+    monkeypatch.delenv("QCAT_HIP_NO_ADAPTER_BITSLICE")
+    diff = np.flatnonzero(recs_b16 != recs)
+    assert diff.size == 0, "default path vs binary16 kernels: %d records differ, first at read %d" % (diff.size, diff[0])
+    assert np.array_equal(cnt, cnt_b16)
+    # the generator is stateless per read index: a batch of the first n reads of the same parameters is the head of r's
+    n = min(n_generic, r.n)
+    sp = native.SynthParams.from_buffer_copy(r.sp)
+    sp.n_reads = n
+    monkeypatch.setenv("QCAT_HIP_FORCE_GENERIC", "1")
+    gctx = native.NativeContext(0)
+    monkeypatch.delenv("QCAT_HIP_FORCE_GENERIC")
+    head = C.c_void_p()
+    r.hip.check(r.lib.qcat_batch_synthesize(gctx.handle, r.kit.handle, C.byref(sp), C.byref(head)))
+    try:
+        r.hip.check(r.lib.qcat_scan_resident(gctx.handle, r.kit.handle, head))
+        recs_gen = np.zeros(n, dtype=native.RESULT_DTYPE)
+        r.hip.check(r.lib.qcat_ctx_fetch_results(gctx.handle, recs_gen.ctypes.data, n))
+    finally:
+        r.lib.qcat_batch_destroy(head)
+    diff = np.flatnonzero(recs_gen != recs[:n])
+    assert diff.size == 0, "default path vs general int32 kernel: %d records differ, first at read %d" % (diff.size, diff[0])
 
 
 def test_config2_one_million_reads_5p_only():
@@ -117,14 +150,15 @@ def test_config2_one_million_reads_5p_only():
         r.close()
 
 
-def test_config3_ten_million_reads_both_ends():
+def test_config3_ten_million_reads_both_ends(monkeypatch):
     det = scanner.factory(kit="PBC096")
     r = Resident(det, native.ENDS_BOTH, 10000000, 20260930, 0.08)
     try:
         recs, cnt = r.scan()
         assert cnt[:97].sum() == r.n
         assert np.array_equal(cnt, histogram_from_records(r.desc, det.layouts, recs))
-        check_sample_against_oracle(r, recs, 1500, np.random.default_rng(2))
+        check_sample_against_oracle(r, recs, 50000, np.random.default_rng(2))
+        check_all_records_across_device_paths(r, recs, cnt, monkeypatch)
         # trims are always ordered and inside the read (qcat/test/test_barcode.py:599-603 style)
         assert (recs["trim5p"] <= recs["trim3p"]).all() and (recs["trim5p"] >= 0).all()
         called = recs["barcode_idx"] >= 0
@@ -132,6 +166,49 @@ def test_config3_ten_million_reads_both_ends():
         assert set(np.unique(recs["exit_status"])) <= {0, 1, 1002}
     finally:
         r.close()
+
+
+def test_config4_shard_twelve_and_a_half_million_reads(monkeypatch):
+    """BASELINE config 4 = 100 M PBC096 reads over 8 GPUs: ONE rank's shard (12.5 M reads, the seed rank 3 of
+    bench.py --gpus 8 uses) at full size, every record cross-checked over the device paths, 50 k through the oracle."""
+    det = scanner.factory(kit="PBC096")
+    r = Resident(det, native.ENDS_BOTH, 12500000, 20260928 + 3 + 1000003 * 3, 0.08)
+    try:
+        recs, cnt = r.scan()
+        assert cnt[:97].sum() == r.n and cnt[97:100].sum() == r.n
+        assert np.array_equal(cnt, histogram_from_records(r.desc, det.layouts, recs))
+        check_sample_against_oracle(r, recs, 50000, np.random.default_rng(4))
+        check_all_records_across_device_paths(r, recs, cnt, monkeypatch)
+        assert (recs["trim5p"] <= recs["trim3p"]).all() and (recs["trim5p"] >= 0).all()
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 8])
+def test_contiguous_shards_on_one_device_equal_the_whole_batch(n_shards):
+    """The part of configs 4 / 5 that needs no RCCL: `parallel.shard_range` cuts a batch into contiguous
+    shards, every shard is scanned through a context of its own (as a rank would, here all on device 0), the shard
+    count vectors are summed on the host -- what the all-reduce does -- and counts and read-ordered records must equal
+    the oracle's scan of the WHOLE batch."""
+    from qcat_amd import parallel
+    det = scanner.factory(kit="PBC096")
+    n = 30011                                                    # (not a multiple of the shard count)
+    reads = synth.synth_batch(n, 20260931, det.layouts, 1, 0, error_rate=0.08) + ["", "A", "N" * 200]
+    desc = det.descriptor(ends=native.ENDS_BOTH)
+    kit = native.NativeKit(desc)
+    want, want_cnt = oracle_lib.scan(desc, reads, threads=16, counts=True)
+    total = np.zeros(desc.n_count_buckets, dtype=np.int64)
+    parts = []
+    for rank in range(n_shards):
+        lo, hi = parallel.shard_range(len(reads), rank, n_shards)
+        ctx = native.NativeContext(0)
+        bases, offsets = native.pack_reads(reads[lo:hi])
+        cnt = np.zeros(desc.n_count_buckets, dtype=np.int64)
+        parts.append(ctx.scan(kit, bases, offsets, counts=cnt))
+        total += cnt
+    got = np.concatenate(parts)
+    assert got.tobytes() == want.tobytes()
+    assert np.array_equal(total, want_cnt) and total[:97].sum() == len(reads)
 
 
 def test_error_free_reads_recover_their_barcode():

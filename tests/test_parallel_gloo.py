@@ -144,3 +144,69 @@ def test_bench_refuses_more_gpus_than_devices():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr
+
+
+def test_two_jobs_of_one_world_size_do_not_cross_connect(tmp_path):
+    """Per-job nonce in the rendezvous: a rank of job B that probes job A's server (same world size, neighbouring
+    port) gets no id and is not counted by A; B's own server answers it."""
+    import socket
+    import struct
+    import threading
+    base = parallel.free_port()
+    env_a = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(base), "QCAT_RDZV_NONCE": "job-a"}
+    env_b = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(base), "QCAT_RDZV_NONCE": "job-b"}
+    assert parallel.job_nonce(env_a) != parallel.job_nonce(env_b) and len(parallel.job_nonce(env_a)) == 8
+    got = {}
+
+    def run(tag, env, rank, payload):
+        try:
+            got[(tag, rank)] = parallel.exchange_id(rank, 2, lambda: payload, environ=env, timeout=60.0)
+        except Exception as exc:                      # noqa: BLE001 -- reported through the assertion below
+            got[(tag, rank)] = exc
+    ts = [threading.Thread(target=run, args=("a", env_a, 0, b"A" * 128))]
+    ts[0].start()
+    import time
+    time.sleep(0.3)                                   # A's server holds the first candidate port
+    ts += [threading.Thread(target=run, args=("b", env_b, 0, b"B" * 128)),
+           threading.Thread(target=run, args=("b", env_b, 1, None))]
+    for t in ts[1:]:
+        t.start()
+    time.sleep(0.5)
+    ts.append(threading.Thread(target=run, args=("a", env_a, 1, None)))
+    ts[-1].start()
+    for t in ts:
+        t.join(timeout=90)
+    assert got[("a", 0)] == got[("a", 1)] == b"A" * 128
+    assert got[("b", 0)] == got[("b", 1)] == b"B" * 128
+    # a request without the nonce (a rank of an older build, a port scanner) is not served either
+    assert struct.calcsize("<ii") == 8 and socket is not None
+
+
+def test_rank_cpu_plan_splits_nodes_and_quota():
+    """launch(): rank r sits on the CPUs of its GPU's NUMA node, ranks sharing a node split it, and the host threads
+    per rank are the container's usable CPUs / ranks (16-core quota, 8 ranks -> 2 threads each, no oversubscription)."""
+    node_cpus = {0: range(0, 64), 1: range(64, 128)}
+    plan = parallel.rank_cpu_plan(8, numa_nodes=[0, 0, 0, 0, 1, 1, 1, 1], affinity=range(128), quota=16.0, node_cpus=node_cpus)
+    assert [t for _c, t in plan] == [2] * 8
+    seen = set()
+    for r, (cpus, _t) in enumerate(plan):
+        assert len(cpus) == 16 and set(cpus) <= set(node_cpus[r // 4]) and not (set(cpus) & seen)
+        seen |= set(cpus)
+    # unknown topology: the whole affinity mask, threads still split
+    plan = parallel.rank_cpu_plan(4, numa_nodes=None, affinity=range(8), quota=None)
+    assert [len(c) for c, _t in plan] == [8] * 4 and [t for _c, t in plan] == [2] * 4
+    # more ranks than CPUs: one thread each, never zero
+    assert [t for _c, t in parallel.rank_cpu_plan(8, affinity=range(2), quota=1.0)] == [1] * 8
+
+
+def test_bench_gpus8_on_a_small_box_fails_fast():
+    """bench.py --gpus 8 where fewer than 8 devices are visible: the device-count message, quickly, no rank started."""
+    import time
+    if native.HipLibrary.get().lib.qcat_device_count() >= 8:
+        pytest.skip("8-GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and b"--gpus 8 but only" in p.stderr and p.stdout.strip() == b""
+    assert time.time() - t0 < 20.0            # (seconds of interpreter + library start, no scan: 2 s on a warm box)
