@@ -1,0 +1,134 @@
+// abs_host_check.cpp -- host check of the bit-sliced adapter arithmetic (test infrastructure, plain g++).
+//
+// qcat_amd/csrc/abs_core.h and the generated column programs (abs_generated.inc) are pure functions of 32-bit words,
+// so the code the device kernels run is executed here 32 alignments at a time and compared, alignment by alignment,
+// with the oracle's scalar DP (oracle/qcat_oracle.c: qo_sg, the restatement of parasail's semi-global alignment with
+// the end-position rule R1).  Built and run by tests/test_abs_host.py:
+//     g++ -O2 -std=c++17 -I qcat_amd/csrc tests/abs_host_check.cpp -o <tmp>/abs_host_check -L oracle -lqcat_oracle
+//     abs_host_check <seed> <rounds>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "abs_core.h"
+#include "abs_generated.inc"
+
+extern "C" int qo_sg(const char* s1, int L, const char* s2, int M, int open, int extend, const int8_t* mat,
+                     int32_t* score, int32_t* end_query, int32_t* end_ref);
+
+using namespace qabs;
+
+static uint64_t g_s;
+static uint64_t rnd() { g_s += 0x9E3779B97F4A7C15ull; uint64_t z = g_s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+static int below(int n) { return (int)((rnd() >> 33) % (uint64_t)n); }
+static const char BASES[] = "ATGC";                 // plane codes 0..3 (qcat_amd/codes.py)
+
+static void adapter_matrix(int8_t* m) {             // qcat/config.py:236-253, [target code * 7 + query code]; codes A T G C N X other
+    for (int t = 0; t < 7; ++t)
+        for (int q = 0; q < 7; ++q) {
+            int v;
+            if (t == 6 || q == 6) v = 0;
+            else if (t == 5 || q == 5) v = 0;
+            else if (t == 4 || q == 4) v = -1;
+            else v = t == q ? 5 : -2;
+            m[t * 7 + q] = (int8_t)v;
+        }
+}
+
+static std::string make_window(const std::string* tpls, int nt, int L) {
+    std::string w;
+    const int kind = below(10);
+    if (kind == 0) {                                 // homopolymer / short tandem repeat: ties everywhere
+        const int p = 1 + below(3);
+        char unit[4];
+        for (int i = 0; i < p; ++i) unit[i] = BASES[below(4)];
+        for (int i = 0; i < L; ++i) w.push_back(unit[i % p]);
+        return w;
+    }
+    if (kind == 1) {                                 // adapter-free
+        for (int i = 0; i < L; ++i) w.push_back(BASES[below(4)]);
+        return w;
+    }
+    const std::string& t = tpls[below(nt)];
+    const int lead = below(60);
+    for (int i = 0; i < lead; ++i) w.push_back(BASES[below(4)]);
+    const int err = below(25);                       // per cent
+    const int from = kind == 2 ? below((int)t.size()) : 0;          // sometimes only a suffix of the adapter
+    for (size_t j = (size_t)from; j < t.size(); ++j) {
+        const char c = t[j] == 'N' ? BASES[below(4)] : t[j];
+        if (below(100) < err) {
+            const int k = below(3);
+            if (k == 0) w.push_back(BASES[below(4)]);
+            else if (k == 2) { w.push_back(BASES[below(4)]); w.push_back(c); }
+        } else w.push_back(c);
+    }
+    while ((int)w.size() < L) w.push_back(BASES[below(4)]);
+    w.resize((size_t)L);
+    return w;
+}
+
+template <class P>
+static int check_plan(const char* name, const std::string* tpls, int rounds, int L) {
+    int8_t mat[49];
+    adapter_matrix(mat);
+    int bad = 0;
+    for (int r = 0; r < rounds; ++r) {
+        std::vector<std::string> win(32);
+        for (auto& w : win) w = make_window(tpls, P::NT, L);
+        // letter planes of the 32 alignments
+        std::vector<u32> c1((size_t)L), c0((size_t)L);
+        for (int i = 0; i < L; ++i)
+            for (int b = 0; b < 32; ++b) {
+                const int code = (int)(strchr(BASES, win[(size_t)b][(size_t)i]) - BASES);
+                c1[(size_t)i] |= (u32)((code >> 1) & 1) << b;
+                c0[(size_t)i] |= (u32)(code & 1) << b;
+            }
+        static u32 h0[P::NC0][4], h1[P::NC1][4];
+        for (int j = 0; j < P::NC0; ++j) abs_set2(h0[j]);
+        for (int j = 0; j < P::NC1; ++j) abs_set2(h1[j]);
+        AbsBorder bd[P::NT];
+        memset(bd, 0, sizeof bd);
+        for (int i = 0; i < L; ++i) {
+            u32 nq[4], ho[P::NH][4];
+            abs_neq_masks(c1[(size_t)i], c0[(size_t)i], nq);
+            P::row0(nq, h0, ho);
+            P::row1(nq, h1, ho, bd, i == 0 ? 0xFFFFFFFFu : 0u, (unsigned)i);
+        }
+        AbsLastRow lo[P::NH], lr[P::NT];
+        P::last0(h0, lo);
+        P::last1(h1, lo, lr);
+        for (int t = 0; t < P::NT; ++t) {
+            u32 val[ABS_NF + 1], endq[ABS_NI];
+            abs_decide(bd[t], lr[t], (unsigned)(L - 1), val, endq);
+            const int M = (int)tpls[t].size();
+            for (int b = 0; b < 32; ++b) {
+                int v = 0, e = 0;
+                for (int k = 0; k <= ABS_NF; ++k) v |= (int)((val[k] >> b) & 1u) << k;
+                for (int k = 0; k < ABS_NI; ++k) e |= (int)((endq[k] >> b) & 1u) << k;
+                const int score = v - 2 * M - 1;
+                int32_t ws, wq, wr;
+                qo_sg(win[(size_t)b].c_str(), L, tpls[t].c_str(), M, 2, 2, mat, &ws, &wq, &wr);
+                if (score != ws || e != wq) {
+                    if (bad < 10)
+                        fprintf(stderr, "%s round %d template %d alignment %d: got (%d, %d), oracle (%d, %d)\n  %s\n", name, r, t, b,
+                                score, e, ws, wq, win[(size_t)b].c_str());
+                    ++bad;
+                }
+            }
+        }
+    }
+    printf("%s: %d rounds x 32 alignments x %d template(s), L = %d: %d mismatches\n", name, rounds, P::NT, L, bad);
+    return bad;
+}
+
+struct Seqs { const char* a; const char* b; };
+
+int main(int argc, char** argv) {
+    g_s = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 20;
+    int bad = 0;
+#include "abs_host_cases.inc"
+    return bad ? 1 : 0;
+}

@@ -546,3 +546,64 @@ def test_bit_sliced_shapes_of_custom_kits(letters, tmp_path, monkeypatch):
         bad = np.nonzero(got != want)[0]
         assert len(bad) == 0, (name, bad[:10], got[bad[:3]], want[bad[:3]])
         assert np.array_equal(cnt, want_cnt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,kit,ends", [("epi2me", "PBC096", native.ENDS_BOTH), ("epi2me", "NBD103/NBD104", native.ENDS_5P),
+                                           ("epi2me", "PBK004/LWB001", native.ENDS_BOTH), ("epi2me", None, native.ENDS_BOTH),
+                                           ("epi2me", "RBK001", native.ENDS_BOTH), ("dual", None, native.ENDS_BOTH)])
+def test_bit_sliced_adapter_kernels_equal_the_binary16_kernels_and_the_oracle(mode, kit, ends, monkeypatch):
+    """The bit-sliced adapter kernels (kernels_abs.inc) take the full-length windows of plain A/C/G/T of a big batch, the
+    binary16 kernels of the same kit the 128-end tiles that hold anything else.  A debug scan of a mixed batch (plain
+    reads, reads with N / IUPAC letters / lower case, reads shorter than two windows, degenerate reads) compares the
+    per-template raw score AND end_query of every window (trace), every per-barcode row and the records with the
+    oracle -- with the path forced, and with it switched off.  Templates without a plan (too long for two stages: the
+    98-column template of the dual kit) simply stay on the binary16 kernels beside the ones that have one."""
+    det = scanner.factory(mode=mode, kit=kit)
+    t5 = len(det.layouts) - 1 if kit else (3 if mode == "epi2me" else 1)
+    t3 = 0 if len(det.layouts) > 1 else -1
+    if kit is None and mode == "epi2me":
+        t3 = 2
+    n = 9000
+    reads = synth.synth_batch(n, 4242, det.layouts, t5, t3, error_rate=0.08)
+    for i in range(0, n, 7):
+        r = reads[i]
+        k = (i // 7) % 6
+        if k == 0:
+            reads[i] = r[:40] + "N" + r[41:70] + "NN" + r[72:]
+        elif k == 1:
+            reads[i] = r[:60] + "R" + r[61:]
+        elif k == 2:
+            reads[i] = r[:20 + (i % 290)]                        # shorter than two windows, many shorter than one
+        elif k == 3:
+            reads[i] = r[:-30] + "n" + r[-29:]
+        elif k == 4:
+            reads[i] = r.lower()
+        else:
+            reads[i] = ("ACG" * 80)[:150 + i % 50]               # tandem repeat: ties in the end-position rule
+    reads[3], reads[4], reads[5] = "", "N" * 400, "A" * 300
+    d = det.descriptor(ends=ends)
+    o_recs, o_cnt, o_traces, o_rows = oracle_lib.scan(d, reads, counts=True, trace=True, rows=True, threads=16)
+    bases, offsets = native.pack_reads(reads)
+    lib = native.HipLibrary.get().lib
+    has_plan = True                                             # (dual kit: its 83-column template has one, the 98-column one not)
+    for variant in ("forced", "off"):
+        if variant == "forced":
+            monkeypatch.setenv("QCAT_HIP_ADAPTER_BITSLICE_MIN", "1")
+        else:
+            monkeypatch.setenv("QCAT_HIP_NO_ADAPTER_BITSLICE", "1")
+        cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+        ctx = native.NativeContext(0)
+        native.HipLibrary.get().check(lib.qcat_ctx_set_timing(ctx.handle, 1))
+        recs, traces, rows = ctx.scan(native.NativeKit(d), bases, offsets, counts=cnt, trace=True, rows=True)
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        ran = [names[i].decode() for i in range(lib.qcat_ctx_last_timing(ctx.handle, names, ms, 16))]
+        assert ("k_adapter_bitslice" in ran) == (variant == "forced" and has_plan), (variant, ran)
+        for name in native.TRACE_DTYPE.names:
+            bad = np.nonzero(np.asarray(traces[name] != o_traces[name]).reshape(len(traces), -1).any(axis=1))[0]
+            assert len(bad) == 0, (variant, name, bad[:10], traces[name][bad[:3]], o_traces[name][bad[:3]])
+        assert np.array_equal(rows, o_rows)
+        bad = np.nonzero(recs != o_recs)[0]
+        assert len(bad) == 0, (variant, bad[:10], recs[bad[:3]], o_recs[bad[:3]])
+        assert np.array_equal(cnt, o_cnt)

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generate qcat_amd/csrc/abs_generated.inc: the bit-sliced ADAPTER kernels' column programs for the built-in kits
+(kernels_abs.inc, abs_core.h).
+
+A plan is what ONE pass over a read window computes: the two templates of a kit that has a fused binary16 kernel
+(tools/gen_static_kernels.py: `fused`, same ids) -- their common prefix once, then each tail -- or a single template.
+The pass is a linear program over the template columns
+
+    start, col.. (shared prefix), fork, col.. (tail A), border A, resume, col.. (tail B), border B
+
+cut into TWO stages of about equal instruction count: stage 0 and stage 1 run on two waves of a workgroup, the
+differences `a` that cross the cut (the running one and, when the cut falls between fork and resume, the forked one)
+travel through the LDS row by row.  Every border (last column of a template) must fall into stage 1, which owns the
+end-position state.  The generator writes, per plan, four straight-line functions over the primitives of abs_core.h:
+row0 / row1 (one DP row of each stage) and last0 / last1 (the walk along the last row).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import gen_static_kernels as gsk  # noqa: E402
+
+OUT = os.path.join(ROOT, "qcat_amd", "csrc", "abs_generated.inc")
+CASES_OUT = os.path.join(ROOT, "tests", "abs_host_cases.inc")
+LETTER = {"A": 0, "T": 1, "G": 2, "C": 3}          # qcat_amd/codes.py: the plane code of a letter
+COST = {"L": 27, "N": 25, "border": 52, "handover": 10}
+MAX_STAGE_COLUMNS = 46                              # 4 planes per column + ~60 working registers <= 256 VGPRs (two waves per SIMD)
+
+
+def program(seqs):
+    """linear program of a plan: list of ops"""
+    if len(seqs) == 1:
+        return [("start",)] + [("col", c) for c in seqs[0]] + [("border", 0)]
+    sa, sb = seqs
+    u = len(os.path.commonprefix([sa, sb]))
+    if u == 0:
+        return ([("start",)] + [("col", c) for c in sa] + [("border", 0)] +
+                [("start",)] + [("col", c) for c in sb] + [("border", 1)])
+    return ([("start",)] + [("col", c) for c in sa[:u]] + [("fork",)] + [("col", c) for c in sa[u:]] + [("border", 0)] +
+            [("resume",)] + [("col", c) for c in sb[u:]] + [("border", 1)])
+
+
+def op_cost(op):
+    if op[0] == "col":
+        return COST["N"] if op[1] == "N" else COST["L"]
+    if op[0] == "border":
+        return COST["border"]
+    return 0
+
+
+def split_point(ops):
+    """index p: ops[:p] = stage 0.  Balanced by the cost model, no border in stage 0, cut only after a column."""
+    total = sum(op_cost(o) for o in ops)
+    first_border = min(i for i, o in enumerate(ops) if o[0] == "border")
+    best, best_p, run = None, None, 0
+    for i, o in enumerate(ops):
+        run += op_cost(o)
+        if o[0] != "col" or i + 1 > first_border:
+            continue
+        nxt = ops[i + 1][0]
+        if nxt in ("border",):
+            continue                                   # the border belongs with its column's stage (stage 1)
+        live = 1 + (1 if any(x[0] == "fork" for x in ops[:i + 1]) and any(x[0] == "resume" for x in ops[i + 1:]) else 0)
+        if nxt == "fork":
+            live = 1                                   # cut right before the fork: stage 1 forks itself
+        s0 = run + COST["handover"] * live
+        s1 = total - run + COST["handover"] * live
+        score = max(s0, s1)
+        if best is None or score < best:
+            best, best_p = score, i + 1
+    return best_p
+
+
+def emit_plan(name, seqs, comment):
+    ops = program(seqs)
+    p = split_point(ops)
+    s0, s1 = ops[:p], ops[p:]
+    fork_in_0 = any(o[0] == "fork" for o in s0)
+    resume_in_1 = any(o[0] == "resume" for o in s1)
+    fork_live = fork_in_0 and resume_in_1
+    nh = 2 if fork_live else 1
+    nc0 = sum(1 for o in s0 if o[0] == "col")
+    nc1 = sum(1 for o in s1 if o[0] == "col")
+    nt = len(seqs)
+    if max(nc0, nc1) > MAX_STAGE_COLUMNS:
+        return None                                   # the stage's difference planes would not fit a wave's registers
+    cur_slot = nh - 1                                 # hand-over slot of the running difference; slot 0 = the forked one
+    out = []
+    out.append("// %s\n" % comment)
+    for i, q in enumerate(seqs):
+        out.append("//   template %d (%d columns): %s\n" % (i, len(q), q))
+    out.append("//   stage 0: %d columns, stage 1: %d columns, %d hand-over set%s, cost model %d / %d instructions per row\n"
+               % (nc0, nc1, nh, "s" if nh > 1 else "",
+                  sum(op_cost(o) for o in s0), sum(op_cost(o) for o in s1)))
+    out.append("struct %s {\n" % name)
+    out.append("    static constexpr int NT = %d, NH = %d, NC0 = %d, NC1 = %d;\n" % (nt, nh, nc0, nc1))
+    out.append("    static constexpr int M0 = %d, M1 = %d;\n" % (len(seqs[0]), len(seqs[1]) if nt > 1 else 0))
+
+    def cell(j, c):
+        if c == "N":
+            return "abs_cell_n(a, h[%d]);" % j
+        return "abs_cell_letter(nq[%d], a, h[%d]);" % (LETTER[c], j)
+
+    # ---- row0 ----
+    body, j = [], 0
+    for o in s0:
+        if o[0] == "start":
+            body.append("abs_set2(a);")
+        elif o[0] == "col":
+            body.append(cell(j, o[1])); j += 1
+        elif o[0] == "fork":
+            body.append("ABS_COPY4(f, a);")
+    if fork_live:
+        body.append("ABS_COPY4(ho[0], f);")
+    body.append("ABS_COPY4(ho[%d], a);" % cur_slot)
+    out.append("    static ABS_FN void row0(const u32 (&nq)[4], u32 (&h)[NC0][4], u32 (&ho)[NH][4]) {\n"
+               "        u32 a[4]%s;\n        %s\n    }\n" % (", f[4]" if fork_in_0 else "", "\n        ".join(body)))
+    # ---- row1 ----
+    body, j = ["ABS_COPY4(a, hi[%d]);" % cur_slot], 0
+    if fork_live:
+        body.append("ABS_COPY4(f, hi[0]);")
+    for o in s1:
+        if o[0] == "start":
+            body.append("abs_set2(a);")
+        elif o[0] == "col":
+            body.append(cell(j, o[1])); j += 1
+        elif o[0] == "fork":
+            body.append("ABS_COPY4(f, a);")
+        elif o[0] == "resume":
+            body.append("ABS_COPY4(a, f);")
+        elif o[0] == "border":
+            body.append("{ const u32 nm = abs_border_step(bd[%d].Fc, a, first); abs_latch_index(bd[%d].ic, nm, row); }" % (o[1], o[1]))
+    need_f1 = fork_live or any(o[0] == "fork" for o in s1)
+    out.append("    static ABS_FN void row1(const u32 (&nq)[4], u32 (&h)[NC1][4], const u32 (&hi)[NH][4], AbsBorder (&bd)[NT], u32 first, unsigned row) {\n"
+               "        u32 a[4]%s;\n        %s\n    }\n" % (", f[4]" if need_f1 else "", "\n        ".join(body)))
+    # ---- last0 / last1: the walk along the last row, same program over the b planes ----
+    body, j, first = [], 0, False
+    for o in s0:
+        if o[0] == "start":
+            body.append("abs_lastrow_init(r);"); first = True
+        elif o[0] == "col":
+            body.append("abs_lastrow_step(r, h[%d], %s);" % (j, "true" if first else "false")); j += 1; first = False
+        elif o[0] == "fork":
+            body.append("rf = r;")
+    if fork_live:
+        body.append("lo[0] = rf;")
+    body.append("lo[%d] = r;" % cur_slot)
+    out.append("    static ABS_FN void last0(const u32 (&h)[NC0][4], AbsLastRow (&lo)[NH]) {\n"
+               "        AbsLastRow r%s;\n        %s\n    }\n" % (", rf" if fork_in_0 else "", "\n        ".join(body)))
+    body, j, first = ["r = li[%d];" % cur_slot], 0, False
+    if fork_live:
+        body.append("rf = li[0];")
+    for o in s1:
+        if o[0] == "start":
+            body.append("abs_lastrow_init(r);"); first = True
+        elif o[0] == "col":
+            body.append("abs_lastrow_step(r, h[%d], %s);" % (j, "true" if first else "false")); j += 1; first = False
+        elif o[0] == "fork":
+            body.append("rf = r;")
+        elif o[0] == "resume":
+            body.append("r = rf;")
+        elif o[0] == "border":
+            body.append("lr[%d] = r;" % o[1])
+    out.append("    static ABS_FN void last1(const u32 (&h)[NC1][4], const AbsLastRow (&li)[NH], AbsLastRow (&lr)[NT]) {\n"
+               "        AbsLastRow r%s;\n        %s\n    }\n" % (", rf" if need_f1 else "", "\n        ".join(body)))
+    out.append("};\n\n")
+    return "".join(out)
+
+
+def render():
+    _fams, templates, fused, _members = gsk.collect()
+    out = ["// generated by tools/gen_abs_kernels.py -- do not edit.  Column programs of the bit-sliced adapter kernels\n"
+           "// (kernels_abs.inc) for the built-in kits: QAB_F<n> = the fused two-template kit n of static_generated.inc\n"
+           "// (g_static_fused[n]), QAB_T<n> = adapter template n (g_static_templates, kernel n).\n"
+           "#define ABS_COPY4(D, S) do { (D)[0] = (S)[0]; (D)[1] = (S)[1]; (D)[2] = (S)[2]; (D)[3] = (S)[3]; } while (0)\n"
+           "namespace qabs {\n\n"]
+    have_f, have_t = [], []
+    cases = ["// generated by tools/gen_abs_kernels.py -- do not edit.  The plans of abs_generated.inc with their template\n"
+             "// sequences, for tests/abs_host_check.cpp (rows: a full window, and an odd length).\n"]
+
+    def case(name, seqs):
+        cases.append("{ const std::string t[%d] = {%s};\n  bad += check_plan<%s>(\"%s\", t, rounds, 150); bad += check_plan<%s>(\"%s\", t, rounds / 4 + 1, 97); }\n"
+                     % (len(seqs), ", ".join('"%s"' % q for q in seqs), name, name, name, name))
+    for fid, (sa, sb) in enumerate(fused):
+        u = len(os.path.commonprefix([sa, sb]))
+        text = emit_plan("QAB_F%d" % fid, [sa, sb], "fused kit %d: %d shared columns" % (fid, u))
+        if text:
+            out.append(text); have_f.append(fid); case("QAB_F%d" % fid, [sa, sb])
+    for tid, seq in enumerate(templates):
+        text = emit_plan("QAB_T%d" % tid, [seq], "adapter template %d" % tid)
+        if text:
+            out.append(text); have_t.append(tid); case("QAB_T%d" % tid, [seq])
+    render.cases = "".join(cases)
+    out.append("}  // namespace qabs\n#undef ABS_COPY4\n\n")
+    out.append("// X(id): the plans that exist (templates whose stage would not fit a wave's registers have none)\n")
+    out.append("#define QCAT_ABS_FOR_EACH_FUSED(X) %s\n" % " ".join("X(%d)" % i for i in have_f))
+    out.append("#define QCAT_ABS_FOR_EACH_TEMPLATE(X) %s\n" % " ".join("X(%d)" % i for i in have_t))
+    return "".join(out), len(have_f), len(have_t)
+
+
+def main():
+    text, nf, nt = render()
+    with open(OUT, "w") as fh:
+        fh.write(text)
+    with open(CASES_OUT, "w") as fh:
+        fh.write(render.cases)
+    print("wrote %s: %d fused plans, %d single-template plans" % (OUT, nf, nt))
+
+
+if __name__ == "__main__":
+    main()

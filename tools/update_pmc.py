@@ -65,10 +65,13 @@ def main():
         # scans in the profiled run = dispatches of k_finalize (one per scan)
         n_scans = max([len(v) for k, v in insts.items() if "k_finalize" in k] or [1])
         marks = defaultdict(lambda: {"insts_valu": 0.0, "kernels": []})
+        abs_ran = any("k_adapter_bs" in k for k in insts)          # the adapter phase's mark says which kernels took the batch
         for kname, vals in insts.items():
             m = mark_of(kname)
             if m is None:
                 continue
+            if m == "k_adapter_static" and abs_ran:
+                m = "k_adapter_bitslice"
             marks[m]["insts_valu"] += sum(v for v, _ in vals) / n_scans
             short = kname.split("(")[0][:60]
             if short not in marks[m]["kernels"]:
