@@ -331,6 +331,46 @@ int  qcat_ctx_last_timing(qcat_ctx* ctx, const char** names, float* ms, int cap)
  * a few microseconds per launch). */
 int  qcat_ctx_set_timing(qcat_ctx* ctx, int enabled);
 
+/* ---- native FASTQ ingest and egress (SURVEY.md 8f rank 2 at speed) ----
+ * replaces: the per-file loop of the reference driver, qcat/cli.py:445-563 -- iter_fastx over FastqGeneralIterator
+ * (:235-306), detect_barcode_batch per batch of 4000 reads (:500-513), trimming (:521-526), the minimum-length filter
+ * (:527-530), TSV rows (:408-442) and the per-barcode / annotated FASTQ writers (:309-358).  The histogram (:366-383)
+ * stays with the caller: it gets the records and the skipped flags back.
+ * Only plain four-line ASCII FASTQ files qualify (one title, one sequence, one '+', one quality line per read, no '\r',
+ * no trailing blanks, no byte >= 0x80): qcat_fastq_open answers QCAT_ERR_UNSUPPORTED for anything Biopython would read
+ * differently, and the caller's own parser takes the file. */
+typedef struct qcat_fastq qcat_fastq;
+int  qcat_fastq_open(const char* path, qcat_fastq** out, uint64_t* n_reads, uint64_t* n_bytes);
+void qcat_fastq_close(qcat_fastq* f);
+/* where read r lies in the file (offsets from the first byte): title without '@', sequence; for tests */
+int  qcat_fastq_read_info(const qcat_fastq* f, uint64_t r, uint64_t* title_off, uint32_t* title_len,
+                          uint64_t* seq_off, uint32_t* seq_len);
+typedef struct qcat_demux_opts {
+    int32_t batch_size;        /* reads per detect_barcode_batch call (qcat/cli.py:500: 4000); matters under kit_auto only */
+    int32_t kit_auto;          /* 1: per-batch kit vote + detect_barcode with the voted kit (scanner_base.py:714-733) */
+    int32_t trim;              /* --trim (cli.py:521-526) */
+    int32_t min_read_length;   /* --min-read-length (cli.py:527-530) */
+    int32_t tsv;               /* --tsv: rows to tsv_fd (the caller writes the header line, cli.py:486-487) */
+    int32_t tsv_fd;
+    int32_t out_fd;            /* the annotated stream (-o / stdout) when out_dir is NULL and reads are written */
+    const char* out_dir;       /* -b: one <barcode name>.fastq per barcode (existing directory), or NULL */
+    /* what the writers print, per template of the kit (n_templates entries): AdapterLayout.kit, and per barcode of
+     * sets[0] Barcode.name and Barcode.id; dual mode: the ids of sets[1] as well */
+    const char* const* kit_name;
+    const char* const* const* bc_name;
+    const int32_t* const* bc_id;
+    const int32_t* const* bc2_id;
+} qcat_demux_opts;
+typedef struct qcat_demux_stats {
+    uint64_t n_reads, n_skipped, file_bytes;
+    double parse_s, scan_s, write_s;       /* record splitting; upload + kernels + download; formatting + write() */
+} qcat_demux_stats;
+/* scans every read of the file with `kit` (QCAT_ENDS_BOTH) and writes the outputs; recs[r] / skipped[r] (n_reads entries
+ * each, caller-owned) receive the record of read r and whether the minimum-length filter dropped it.
+ * QCAT_ERR_UNSUPPORTED: simple mode, or kit_auto with a kit whose adapter pass cannot be resumed per kit. */
+int  qcat_fastq_demux(qcat_fastq* f, qcat_ctx* ctx, const qcat_kit* kit, const qcat_demux_opts* opts,
+                      qcat_result* recs, uint8_t* skipped, qcat_demux_stats* stats);
+
 /* ---- multi-GPU: reads are sharded by rank, the count vector is the only exchange ----
  * One communicator per (context, rank); RCCL underneath (librccl is opened on the first call here).
  * Ranks may be processes (one per GPU, the id travels by any side channel: a file, a socket, MPI)

@@ -256,6 +256,100 @@ def histogram_lines(barcode_dist, adapter_dist, total_reads):
     return lines
 
 
+class _FdSink(object):
+    """A descriptor native code can write to for a Python text stream: the stream's own descriptor when it has one
+    (flushed first), else a temporary file whose content is copied into the stream afterwards."""
+
+    def __init__(self, stream):
+        self.stream, self.tmp = stream, None
+        try:
+            stream.flush()
+            self.fd = stream.fileno()
+        except (AttributeError, OSError, ValueError):
+            import tempfile
+            self.tmp = tempfile.TemporaryFile()
+            self.fd = self.tmp.fileno()
+
+    def finish(self):
+        if self.tmp is not None:
+            self.tmp.seek(0)
+            while True:
+                chunk = self.tmp.read(1 << 24)
+                if not chunk:
+                    break
+                self.stream.write(chunk.decode("ascii"))
+            self.tmp.close()
+
+
+def _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_length, qcat_config, tsv_stream):
+    """The read loop of ``qcat_cli`` inside the native library (``qcat_fastq_open`` / ``qcat_fastq_demux``,
+    include/qcat_hip.h).  Returns (barcode_dist, adapter_dist, total, skipped) or None when the file or the kit is
+    outside what the native path covers (then nothing has been written)."""
+    import numpy as np
+    from . import native
+    layouts = detector.layouts
+    if not layouts:
+        return None
+    try:
+        fq = native.FastqFile(reads_fq)
+    except native.FastqFile.Unsupported:
+        return None
+    try:
+        one_kit = len(set(l.kit for l in layouts)) == 1
+        kit_auto = (not nobatch) and not one_kit            # per-batch vote (detect_barcode_batch); one kit: nothing to vote on
+        kit = detector._native_kit(layouts, qcat_config, native.ENDS_BOTH)
+        if out and not os.path.exists(out):
+            os.makedirs(out)
+        tsv_sink = _FdSink(tsv_stream) if tsv else None
+        out_sink = _FdSink(stream) if (not out and not tsv) else None
+        try:
+            recs, skipped, _stats = fq.demux(detector._context(), kit, layouts, detector._native_mode == "dual",
+                                             batch_size=BATCH_SIZE, kit_auto=kit_auto, trim=trim, min_read_length=min_read_length,
+                                             tsv_fd=tsv_sink.fd if tsv_sink else None, out_fd=out_sink.fd if out_sink else None,
+                                             out_dir=out if out else None)
+        except native.FastqFile.Unsupported:
+            return None
+        finally:
+            pass
+        for sink in (tsv_sink, out_sink):
+            if sink:
+                sink.finish()
+    finally:
+        fq.close()
+    # the histograms of qcat/cli.py:366-383 from the records (reads the minimum-length filter dropped are not counted):
+    # bincounts over small integer keys -- template index, and (template, barcode[, second barcode]) packed densely
+    keep = skipped == 0
+    a = recs["adapter_idx"][keep].astype(np.int64)
+    b = recs["barcode_idx"][keep].astype(np.int64)
+    adapter_dist, barcode_dist = {}, {}
+    for t, cnt in enumerate(np.bincount(a + 1, minlength=len(layouts) + 1).tolist()):
+        if cnt:
+            key = layouts[t - 1].kit if t > 0 else "none"
+            adapter_dist[key] = adapter_dist.get(key, 0) + cnt
+    called = b >= 0
+    n_none = int(len(b) - int(called.sum()))
+    if n_none:
+        barcode_dist["none"] = n_none
+    dual = detector._native_mode == "dual"
+    w0 = 1 + max(len(l.get_barcode_set(0) or ()) for l in layouts)
+    w1 = 1 + (max(len(l.get_barcode_set(1) or ()) for l in layouts) if dual else 0)
+    keys = (a[called] * w0 + b[called]) * w1
+    if dual:
+        keys = keys + recs["barcode2_idx"][keep].astype(np.int64)[called]
+    for k, cnt in enumerate(np.bincount(keys, minlength=1).tolist()):
+        if not cnt:
+            continue
+        t, i, j = k // (w0 * w1), (k // w1) % w0, k % w1
+        first = layouts[t].get_barcode_set(0)[i]
+        if dual:
+            second = layouts[t].get_barcode_set(1)[j]
+            name = "barcode{:02d}/{:02d}".format(first.id, second.id)
+        else:
+            name = first.name
+        barcode_dist[name] = barcode_dist.get(name, 0) + cnt
+    return barcode_dist, adapter_dist, fq.n_reads, int(skipped.sum())
+
+
 def qcat_cli(reads_fq, kit, mode, nobatch, out, min_qual, tsv, output, threads, trim, adapter_yaml, quiet,
              filter_barcodes, middle_adapter, min_read_length, qcat_config, device=0, tsv_stream=None):
     """Demultiplex one FASTA/FASTQ file; returns (barcode_dist, adapter_dist, total, skipped)."""
@@ -267,6 +361,22 @@ def qcat_cli(reads_fq, kit, mode, nobatch, out, min_qual, tsv, output, threads, 
         print("name", "length", "barcode", "score", "kit", "adapter_end", "comment", sep="\t", file=tsv_stream)
     fastq = is_fastq(reads_fq)
     stream = open(output, "w") if output else sys.stdout
+    native_done = None
+    if fastq and reads_fq and not middle_adapter and not filter_barcodes and mode in ("epi2me", "dual") \
+            and not os.environ.get("QCAT_AMD_NO_NATIVE_FASTQ"):
+        # plain four-line FASTQ files go through the native ingest / egress (qcat_fastq_demux): same outputs, no Python
+        # string per read; anything else (FASTA, stdin, wrapped or odd records, rare options) stays on the loop below
+        native_done = _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_length, qcat_config, tsv_stream)
+    if native_done is not None:
+        barcode_dist, adapter_dist, total_reads, skipped_reads = native_done
+        if not quiet:
+            for line in histogram_lines(barcode_dist, adapter_dist, total_reads):
+                logging.info(line)
+            if skipped_reads > 0:
+                logging.info("{} reads were skipped due to the min. length filter.".format(skipped_reads))
+        if output:
+            stream.close()
+        return barcode_dist, adapter_dist, total_reads, skipped_reads
     outputs = _Outputs(out, stream, fastq)
     barcode_dist, adapter_dist, total_reads, skipped_reads = {}, {}, 0, 0
     for names, comments, seqs, quals in iter_fastx(reads_fq, fastq, 1 if nobatch else BATCH_SIZE):

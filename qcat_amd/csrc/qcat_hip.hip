@@ -353,6 +353,7 @@ struct qcat_batch {
                                    // up to 19 bytes before / after a read's window
     uint64_t* offsets = nullptr;   // n_reads + 1
     uint32_t* true_len = nullptr;  // window-only batches (batch_upload_windows): the reads' real lengths
+    bool borrowed = false;         // the device buffers belong to a context (host-buffer calls): destroy frees the shell only
 };
 
 extern "C" void qcat_batch_destroy(qcat_batch* b);
@@ -396,6 +397,11 @@ struct qcat_ctx {
     size_t cap_mid_slots = 0, cap_mid_bests = 0;
     uint32_t last_n_reads = 0;
     int last_buckets = 0;
+    // device staging of the host-buffer calls (qcat_scan_batch / _auto / _debug, qcat_detect_kit): grown on demand and
+    // reused -- a 4000-read batch of the reference driver's call shape spent a third of its call in six hipMalloc / hipFree
+    uint8_t* hb_bases = nullptr; size_t cap_hb_bases = 0;
+    uint64_t* hb_offsets = nullptr; uint32_t* hb_len = nullptr; size_t cap_hb_reads = 0;
+    unsigned long long* vote_buf = nullptr;        // 2 * MAX_T counters of the kit vote
     // debug buffers
     int32_t* dbg_tpl = nullptr; size_t cap_dbg_tpl = 0;
     int16_t* dbg_rows = nullptr; size_t cap_dbg_rows = 0;
@@ -435,6 +441,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->wspec); (void)hipFree(c->recs); (void)hipFree(c->results);
     (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows);
+    (void)hipFree(c->hb_bases); (void)hipFree(c->hb_offsets); (void)hipFree(c->hb_len); (void)hipFree(c->vote_buf);
     packed_scratch_free(&c->packed);
     if (c->pin_bases) (void)hipHostFree(c->pin_bases);
     if (c->pin_offsets) (void)hipHostFree(c->pin_offsets);
@@ -711,7 +718,7 @@ extern "C" void qcat_batch_destroy(qcat_batch* b) {
     if (!b) return;
     int cur = 0; (void)hipGetDevice(&cur);
     (void)hipSetDevice(b->device);
-    (void)hipFree(b->bases_alloc); (void)hipFree(b->offsets); (void)hipFree(b->true_len);
+    if (!b->borrowed) { (void)hipFree(b->bases_alloc); (void)hipFree(b->offsets); (void)hipFree(b->true_len); }
     (void)hipSetDevice(cur);
     delete b;
 }
@@ -752,7 +759,7 @@ extern "C" int qcat_batch_upload(qcat_ctx* c, const uint8_t* bases, const uint64
 static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t* bases, const uint64_t* offsets,
                                 uint32_t n_reads, qcat_batch** out) {
     const DevKit& hk = kit->hk.dk;
-    if (hk.scan_middle || n_reads < 4096 || getenv("QCAT_HIP_FULL_UPLOAD"))
+    if (hk.scan_middle || n_reads < 256 || getenv("QCAT_HIP_FULL_UPLOAD"))
         return qcat_batch_upload(c, bases, offsets, n_reads, out);
     if (!c || !offsets || !out || (!bases && offsets[n_reads] > 0)) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
     if (offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
@@ -810,14 +817,24 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
         if (done_to < n_reads) work(done_to, n_reads);
         for (auto& th : pool) th.join();
     }
+    // the context's own device staging (the batch is a view of it: one host-buffer call at a time per context)
+    if (total + 2 * BATCH_SLACK > c->cap_hb_bases) {
+        (void)hipFree(c->hb_bases); c->hb_bases = nullptr; c->cap_hb_bases = 0;
+        const size_t want = (total + 2 * BATCH_SLACK) * 5 / 4;
+        if (hipMalloc((void**)&c->hb_bases, want) != hipSuccess) return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch");
+        c->cap_hb_bases = want;
+    }
+    if ((size_t)n_reads + 1 > c->cap_hb_reads) {
+        (void)hipFree(c->hb_offsets); (void)hipFree(c->hb_len); c->hb_offsets = nullptr; c->hb_len = nullptr; c->cap_hb_reads = 0;
+        const size_t want = ((size_t)n_reads + 1) * 5 / 4;
+        if (hipMalloc((void**)&c->hb_offsets, want * 8) != hipSuccess || hipMalloc((void**)&c->hb_len, want * 4) != hipSuccess)
+            return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch");
+        c->cap_hb_reads = want;
+    }
     qcat_batch* b = new qcat_batch();
     BatchGuard guard(b);
-    b->device = c->device; b->n_reads = n_reads; b->n_bases = total;
-    hipError_t e1 = hipMalloc((void**)&b->bases_alloc, total + 2 * BATCH_SLACK);
-    if (e1 == hipSuccess) b->bases = b->bases_alloc + BATCH_SLACK;
-    hipError_t e2 = hipMalloc((void**)&b->offsets, ((size_t)n_reads + 1) * 8);
-    hipError_t e3 = hipMalloc((void**)&b->true_len, ((size_t)n_reads + 1) * 4);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch");
+    b->device = c->device; b->n_reads = n_reads; b->n_bases = total; b->borrowed = true;
+    b->bases_alloc = c->hb_bases; b->bases = c->hb_bases + BATCH_SLACK; b->offsets = c->hb_offsets; b->true_len = c->hb_len;
     if (total) HIPCHK(hipMemcpyAsync(b->bases, c->pin_bases, total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b->offsets, c->pin_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b->true_len, c->pin_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
@@ -961,12 +978,26 @@ static void fill_trace(const HostKit& hk, const EndRec& r, const int32_t* tplraw
 
 // qcat_scan_batch over host buffers as a chunked pipeline (host_pipeline.inc).  Returns 1 when the batch
 // does not qualify (small, --detect-middle, disabled) and the caller should take the one-shot path.
-static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases, const uint64_t* offsets,
+// where the reads of a host batch lie: concatenated (bases + offsets, the form of qcat_scan_batch) or scattered through a
+// mapped FASTQ file (one FqRec per read, fastq_host.inc) -- the pipeline only ever reads head and tail of a read in place
+namespace qk { struct FqRec { uint64_t title, seq, qual; uint32_t title_len, seq_len; }; }
+struct ReadView {
+    const uint8_t* bases;
+    const uint64_t* offsets;           // concatenated form (recs == nullptr)
+    const qk::FqRec* recs;             // FASTQ form: bases = the mapping, read r = recs[r]
+    inline uint64_t start(uint32_t r) const { return recs ? recs[r].seq : offsets[r]; }
+    inline uint64_t len(uint32_t r) const { return recs ? (uint64_t)recs[r].seq_len : offsets[r + 1] - offsets[r]; }
+};
+
+static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
                                 uint32_t n_reads, qcat_result* out, int64_t* counts) {
     const DevKit& hk = kit->hk.dk;
+    const uint8_t* bases = rv.bases;
     if (hk.scan_middle || n_reads < 32768 || getenv("QCAT_HIP_FULL_UPLOAD") || getenv("QCAT_HIP_NO_PIPELINE")) return 1;
-    if (!bases && offsets[n_reads] > 0) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
-    if (offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
+    if (!rv.recs) {
+        if (!bases && rv.offsets[n_reads] > 0) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
+        if (rv.offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
+    }
     HIPCHK(hipSetDevice(c->device));
     const uint64_t n = (uint64_t)hk.max_align;
     const bool both = hk.ends == QCAT_ENDS_BOTH;
@@ -1061,9 +1092,8 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
             const uint32_t a = std::min<uint32_t>(nr, (uint32_t)part * per), b2 = std::min<uint32_t>(nr, a + per);
             uint64_t sum = 0; int err = 0;
             for (uint32_t r = a; r < b2; ++r) {
-                const uint64_t x = offsets[r0 + r], y = offsets[r0 + r + 1];
-                if (y < x) { err = 1; break; }
-                const uint64_t len = y - x;
+                if (!rv.recs && rv.offsets[r0 + r + 1] < rv.offsets[r0 + r]) { err = 1; break; }
+                const uint64_t len = rv.len(r0 + r);
                 if (len > 0xFFFFFFFFull) { err = 2; break; }
                 sum += len <= keep ? len : keep;
             }
@@ -1084,7 +1114,7 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
             constexpr uint32_t AHEAD = 12;                           // reads: the windows are 150 B out of every ~700, each a cache
             for (uint32_t r = a; r < b2; ++r) {                      // miss the hardware prefetcher does not see coming
                 if (r + AHEAD < b2) {
-                    const uint64_t px = offsets[r0 + r + AHEAD], py = offsets[r0 + r + AHEAD + 1];
+                    const uint64_t px = rv.start(r0 + r + AHEAD), py = px + rv.len(r0 + r + AHEAD);
                     const uint8_t* ps = bases + px;
                     __builtin_prefetch(ps, 0, 0); __builtin_prefetch(ps + 64, 0, 0); __builtin_prefetch(ps + 128, 0, 0);
                     if (both && py - px > keep) {
@@ -1092,8 +1122,8 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const uint8_t* bases
                         __builtin_prefetch(pt, 0, 0); __builtin_prefetch(pt + 64, 0, 0); __builtin_prefetch(pt + 128, 0, 0);
                     }
                 }
-                const uint64_t x = offsets[r0 + r];
-                const uint64_t len = offsets[r0 + r + 1] - x;
+                const uint64_t x = rv.start(r0 + r);
+                const uint64_t len = rv.len(r0 + r);
                 const uint8_t* src = bases + x;
                 uint8_t* dst = st.pin_bases + pos;
                 st.pin_len[r] = (uint32_t)len;
@@ -1196,9 +1226,8 @@ static int vote_resident(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, unsign
     if (rc || !b->n_reads) return rc;
     KitOnDevice* kd = nullptr;
     if ((rc = kit_on_device(kit, c->device, &kd))) return rc;
-    DevTemp vote_buf;
-    HIPCHK(vote_buf.alloc(2 * MAX_T * 8));
-    unsigned long long* d = vote_buf.as<unsigned long long>();
+    if (!c->vote_buf) HIPCHK(hipMalloc((void**)&c->vote_buf, 2 * MAX_T * 8));
+    unsigned long long* d = c->vote_buf;
     HIPCHK(hipMemsetAsync(d, 0, MAX_T * 8, c->stream));
     HIPCHK(hipMemsetAsync(d + MAX_T, 0xFF, MAX_T * 8, c->stream));
     const uint32_t blocks = std::min<uint32_t>((b->n_reads + 255) / 256, 1024);
@@ -1277,7 +1306,8 @@ extern "C" int qcat_scan_batch(qcat_ctx* c, const qcat_kit* kit,
                                const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                                qcat_result* out, int64_t* counts) {
     if (!c || !kit || !offsets || !out) return set_err(QCAT_ERR_ARG, "null argument");
-    const int rc = scan_batch_pipelined(c, const_cast<qcat_kit*>(kit), bases, offsets, n_reads, out, counts);
+    const ReadView rv{bases, offsets, nullptr};
+    const int rc = scan_batch_pipelined(c, const_cast<qcat_kit*>(kit), rv, n_reads, out, counts);
     if (rc <= 0) return rc;                           // done (0) or failed (< 0); 1 = take the one-shot path
     return qcat_scan_debug(c, kit, bases, offsets, n_reads, out, counts, nullptr, nullptr, 0);
 }
@@ -1308,6 +1338,11 @@ extern "C" int qcat_scan_sequences(qcat_ctx* c, const qcat_kit* ckit, const uint
     qcat_batch_destroy(b);
     return rc;
 }
+
+// ------------------------------------------------------------------------------------------
+// native FASTQ ingest and egress
+// ------------------------------------------------------------------------------------------
+#include "fastq_host.inc"
 
 // ------------------------------------------------------------------------------------------
 // multi-GPU count reduction (RCCL)

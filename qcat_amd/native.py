@@ -75,6 +75,19 @@ class SynthParams(C.Structure):
                 ("tpl_5p", C.c_int32), ("tpl_3p", C.c_int32)]
 
 
+class DemuxOpts(C.Structure):
+    """qcat_demux_opts (include/qcat_hip.h)"""
+    _fields_ = [("batch_size", C.c_int32), ("kit_auto", C.c_int32), ("trim", C.c_int32), ("min_read_length", C.c_int32),
+                ("tsv", C.c_int32), ("tsv_fd", C.c_int32), ("out_fd", C.c_int32), ("out_dir", C.c_char_p),
+                ("kit_name", C.POINTER(C.c_char_p)), ("bc_name", C.POINTER(C.POINTER(C.c_char_p))),
+                ("bc_id", C.POINTER(C.POINTER(C.c_int32))), ("bc2_id", C.POINTER(C.POINTER(C.c_int32)))]
+
+
+class DemuxStats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_skipped", C.c_uint64), ("file_bytes", C.c_uint64),
+                ("parse_s", C.c_double), ("scan_s", C.c_double), ("write_s", C.c_double)]
+
+
 class KitDescriptor(object):
     """Owns a ``qcat_kit_desc`` and every buffer it points to.
 
@@ -273,6 +286,10 @@ class HipLibrary(object):
             "qcat_ctx_results_devptr": (vp, [vp]),
             "qcat_ctx_last_timing": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
             "qcat_ctx_set_timing": (C.c_int, [vp, C.c_int]),
+            "qcat_fastq_open": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+            "qcat_fastq_close": (None, [vp]),
+            "qcat_fastq_read_info": (C.c_int, [vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(u32), C.POINTER(C.c_uint64), C.POINTER(u32)]),
+            "qcat_fastq_demux": (C.c_int, [vp, vp, vp, C.POINTER(DemuxOpts), vp, vp, C.POINTER(DemuxStats)]),
             "qcat_comm_unique_id": (C.c_int, [vp]),
             "qcat_comm_create": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
             "qcat_comm_destroy": (None, [vp]),
@@ -503,3 +520,72 @@ class NativeContext(object):
             out.ctypes.data, cptr, traces.ctypes.data,
             bc_rows.ctypes.data if bc_rows is not None else None, stride))
         return out, traces, bc_rows
+
+
+class FastqFile(object):
+    """A FASTQ file mapped and split into records by the native library (qcat_fastq_open): ``n_reads``, ``n_bytes``;
+    raises ``Unsupported`` when the file is not a plain four-line ASCII FASTQ file (the caller's own parser takes it)."""
+
+    class Unsupported(RuntimeError):
+        pass
+
+    def __init__(self, path):
+        self.hip = HipLibrary.get()
+        h, n, nb = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        rc = self.hip.lib.qcat_fastq_open(os.fsencode(path), C.byref(h), C.byref(n), C.byref(nb))
+        if rc == -2:
+            raise FastqFile.Unsupported((self.hip.lib.qcat_last_error() or b"").decode("utf-8", "replace"))
+        self.hip.check(rc)
+        self.handle, self.n_reads, self.n_bytes = h, int(n.value), int(nb.value)
+
+    def read_info(self, r):
+        to, tl, so, sl = C.c_uint64(), C.c_uint32(), C.c_uint64(), C.c_uint32()
+        self.hip.check(self.hip.lib.qcat_fastq_read_info(self.handle, r, C.byref(to), C.byref(tl), C.byref(so), C.byref(sl)))
+        return int(to.value), int(tl.value), int(so.value), int(sl.value)
+
+    def demux(self, ctx, kit, layouts, dual, batch_size=4000, kit_auto=False, trim=False, min_read_length=0,
+              tsv_fd=None, out_fd=None, out_dir=None):
+        """qcat_fastq_demux: scan + write; returns (records, skipped flags, stats dict).  ``layouts``: the AdapterLayout
+        list of ``kit`` (the names the writers print)."""
+        n_t = len(layouts)
+        keep = []
+        kit_names = (C.c_char_p * n_t)(*[str(l.kit).encode() for l in layouts])
+        bc_name = (C.POINTER(C.c_char_p) * n_t)()
+        bc_id = (C.POINTER(C.c_int32) * n_t)()
+        bc2_id = (C.POINTER(C.c_int32) * n_t)()
+        for t, lay in enumerate(layouts):
+            s0 = lay.get_barcode_set(0) or []
+            names = (C.c_char_p * max(1, len(s0)))(*[str(b.name).encode() for b in s0])
+            ids = (C.c_int32 * max(1, len(s0)))(*[int(b.id) for b in s0])
+            s1 = (lay.get_barcode_set(1) or []) if dual else []
+            ids2 = (C.c_int32 * max(1, len(s1)))(*[int(b.id) for b in s1])
+            keep += [names, ids, ids2]
+            bc_name[t] = C.cast(names, C.POINTER(C.c_char_p))
+            bc_id[t] = C.cast(ids, C.POINTER(C.c_int32))
+            bc2_id[t] = C.cast(ids2, C.POINTER(C.c_int32))
+        o = DemuxOpts(batch_size=batch_size, kit_auto=1 if kit_auto else 0, trim=1 if trim else 0,
+                      min_read_length=int(min_read_length), tsv=1 if tsv_fd is not None else 0,
+                      tsv_fd=-1 if tsv_fd is None else tsv_fd, out_fd=-1 if out_fd is None else out_fd,
+                      out_dir=os.fsencode(out_dir) if out_dir else None,
+                      kit_name=C.cast(kit_names, C.POINTER(C.c_char_p)), bc_name=C.cast(bc_name, C.POINTER(C.POINTER(C.c_char_p))),
+                      bc_id=C.cast(bc_id, C.POINTER(C.POINTER(C.c_int32))), bc2_id=C.cast(bc2_id, C.POINTER(C.POINTER(C.c_int32))))
+        recs = np.zeros(self.n_reads, dtype=RESULT_DTYPE)
+        skipped = np.zeros(self.n_reads, dtype=np.uint8)
+        st = DemuxStats()
+        rc = self.hip.lib.qcat_fastq_demux(self.handle, ctx.handle, kit.handle, C.byref(o), recs.ctypes.data, skipped.ctypes.data, C.byref(st))
+        if rc == -2:
+            raise FastqFile.Unsupported((self.hip.lib.qcat_last_error() or b"").decode("utf-8", "replace"))
+        self.hip.check(rc)
+        return recs, skipped, {"n_reads": int(st.n_reads), "n_skipped": int(st.n_skipped), "file_bytes": int(st.file_bytes),
+                               "parse_s": st.parse_s, "scan_s": st.scan_s, "write_s": st.write_s}
+
+    def close(self):
+        if self.handle:
+            self.hip.lib.qcat_fastq_close(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                     # noqa: BLE001 -- interpreter shutdown
+            pass

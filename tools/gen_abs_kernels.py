@@ -26,7 +26,9 @@ import gen_static_kernels as gsk  # noqa: E402
 OUT = os.path.join(ROOT, "qcat_amd", "csrc", "abs_generated.inc")
 CASES_OUT = os.path.join(ROOT, "tests", "abs_host_cases.inc")
 LETTER = {"A": 0, "T": 1, "G": 2, "C": 3}          # qcat_amd/codes.py: the plane code of a letter
-COST = {"L": 27, "N": 25, "border": 52, "handover": 10}
+# instructions per row as compiled (profiles/r03_*): cells 27 / 25, a border step with its index latch 46, a hand-over
+# set 5 LDS instructions on either side; stage 1 also pays the row's LDS reads, masks and loop overhead (+30)
+COST = {"L": 27, "N": 25, "border": 46, "handover": 5, "stage1": 30}
 MAX_STAGE_COLUMNS = 46                              # 4 planes per column + ~60 working registers <= 256 VGPRs (two waves per SIMD)
 
 
@@ -67,7 +69,7 @@ def split_point(ops):
         if nxt == "fork":
             live = 1                                   # cut right before the fork: stage 1 forks itself
         s0 = run + COST["handover"] * live
-        s1 = total - run + COST["handover"] * live
+        s1 = total - run + COST["handover"] * live + COST["stage1"]
         score = max(s0, s1)
         if best is None or score < best:
             best, best_p = score, i + 1
