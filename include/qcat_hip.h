@@ -271,6 +271,19 @@ int  qcat_scan_batch_auto(qcat_ctx* ctx, const qcat_kit* kit,
 int  qcat_scan_sequences(qcat_ctx* ctx, const qcat_kit* kit,
                          const uint8_t* bases, const uint64_t* offsets, uint32_t n_seqs, qcat_result* out);
 
+/* replaces: parasail_sg / parasail_sg_stat as the reference's module-level helpers call them -- align_adapter
+ * (qcat/scanner_base.py:191-220), align_adapter_identity (:144-188), find_highest_scoring_barcode (:108-117): n independent
+ * semi-global alignments of query i = queries[q_offsets[i] .. q_offsets[i+1]) against target i (ASCII, any case; targets
+ * up to QCAT_MAX_TEMPLATE_LEN letters), affine gaps, `matrix`[target code * 7 + query code] over the codes above.
+ * score / end_query / end_ref follow rule R1 (oracle/qcat_oracle.c:100-108); with_stats != 0 also fills `matches` (exact
+ * letter matches) and `length` (alignment columns) along one optimal path -- parity with parasail unpinned for these two
+ * (no scanner path consumes them, scanner_base.py:141).  An empty query or target gives end_query = end_ref = -1. */
+typedef struct qcat_alignment { int32_t score, end_query, end_ref, matches, length; } qcat_alignment;
+int  qcat_sg_align(qcat_ctx* ctx, const uint8_t* queries, const uint64_t* q_offsets,
+                   const uint8_t* targets, const uint64_t* t_offsets, uint32_t n,
+                   int32_t gap_open, int32_t gap_extend, const int8_t* matrix /* 49 */, int32_t with_stats,
+                   qcat_alignment* out);
+
 /* Same, plus one qcat_end_trace per scanned read end (2*n_reads entries, 5' then 3' per read;
  * n_reads entries with QCAT_ENDS_5P) and, if bc_rows != NULL, the raw score of EVERY barcode
  * alignment: bc_rows[((end * 2 + set) * row_stride) + b], row_stride >= largest set. */

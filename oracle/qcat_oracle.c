@@ -7,6 +7,8 @@
  * It follows the reference's Python line by line (citations are into /root/reference):
  *   qo_sg                      parasail.sg_striped_32 as called at qcat/scanner_base.py:111-117,
  *                              :214-218 (algorithm restated, see PARITY below)
+ *   qo_sg_stats                parasail.sg_stats_striped_32 (scanner_base.py:168-172): qo_sg + matches / length
+ *                              along one optimal path -- tie order of tests/golden/sg_independent.py, parity unpinned
  *   qo_window                  extract_align_sequence      qcat/scanner_base.py:223-244
  *                              + utils.revcomp             qcat/utils.py:20-21
  *   qo_find_best_template      find_best_adapter_template  qcat/scanner_base.py:313-359
@@ -120,6 +122,62 @@ int qo_sg(const char* s1, int L, const char* s2, int M, int open, int extend,
     qo_sg_codes(q, L, t, M, open, extend, mat, &a);
     free(q);
     *score = a.score; *end_query = a.end_query; *end_ref = a.end_ref;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * parasail.sg_stats_striped_32 as called at qcat/scanner_base.py:168-172 (align_adapter_identity) and :108-117
+ * (find_highest_scoring_barcode with compute_identity): the alignment of qo_sg plus the number of exact matches and of
+ * alignment columns along ONE optimal path.  PARITY UNPINNED for `matches` / `length`: which of several optimal paths
+ * parasail walks is not documented and parasail is absent here; the tie order restated is the one of
+ * tests/golden/sg_independent.py (diagonal first, then the gap that consumes a target letter, then the gap that consumes a
+ * query letter; an opened gap wins over an extended one only when strictly better).  Nothing on any scanner path
+ * consumes the two numbers (scanner_base.py:141 returns the score in their place).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct qo_stats { int32_t score, end_query, end_ref, matches, length; } qo_stats;
+
+int qo_sg_stats(const char* s1, int L, const char* s2, int M, int open, int extend, const int8_t* mat, qo_stats* out) {
+    qo_init_tables();
+    if (L <= 0 || M <= 0 || L > QO_MAXW || M > QCAT_MAX_TEMPLATE_LEN) {
+        snprintf(qo_err, sizeof qo_err, "qo_sg_stats: bad lengths %d x %d", L, M);
+        return QCAT_ERR_ARG;
+    }
+    /* per target column j: H, the gap state that consumes query letters (from the row above) and their statistics */
+    int32_t H[QCAT_MAX_TEMPLATE_LEN + 2], F[QCAT_MAX_TEMPLATE_LEN + 2];
+    int32_t HM[QCAT_MAX_TEMPLATE_LEN + 2], HL[QCAT_MAX_TEMPLATE_LEN + 2], FM[QCAT_MAX_TEMPLATE_LEN + 2], FL[QCAT_MAX_TEMPLATE_LEN + 2];
+    for (int j = 0; j <= M; ++j) { H[j] = 0; F[j] = QO_NEG; HM[j] = HL[j] = FM[j] = FL[j] = 0; }
+    int32_t cmax = QO_NEG, cfirst = 0, cm = 0, cl = 0;
+    for (int i = 1; i <= L; ++i) {
+        const int qc = qo_code_of[(uint8_t)s1[i - 1]];
+        int32_t diag = H[0], dm = HM[0], dl = HL[0];           /* cell (i-1, 0): 0 with empty statistics */
+        int32_t hleft = 0, hlm = 0, hll = 0;                     /* cell (i, 0) */
+        int32_t e = QO_NEG, em = 0, el = 0;                      /* gap that consumes target letters, along the row */
+        for (int j = 1; j <= M; ++j) {
+            const int tc = qo_code_of[(uint8_t)s2[j - 1]];
+            /* gap consuming a target letter: from (i, j-1) */
+            if (hleft - open > e - extend) { e = hleft - open; em = hlm; el = hll + 1; }
+            else { e = e - extend; el = el + 1; }
+            /* gap consuming a query letter: from (i-1, j) */
+            int32_t f, fm, fl;
+            if (H[j] - open > F[j] - extend) { f = H[j] - open; fm = HM[j]; fl = HL[j] + 1; }
+            else { f = F[j] - extend; fm = FM[j]; fl = FL[j] + 1; }
+            int32_t h = diag + mat[tc * 7 + qc];
+            int32_t hm = dm + ((qo_code_of[(uint8_t)s1[i - 1]] == qo_code_of[(uint8_t)s2[j - 1]] &&
+                                ((s1[i - 1] | 0x20) == (s2[j - 1] | 0x20))) ? 1 : 0);
+            int32_t hl = dl + 1;
+            if (e > h) { h = e; hm = em; hl = el; }
+            if (f > h) { h = f; hm = fm; hl = fl; }
+            diag = H[j]; dm = HM[j]; dl = HL[j];
+            H[j] = h; HM[j] = hm; HL[j] = hl; F[j] = f; FM[j] = fm; FL[j] = fl;
+            hleft = h; hlm = hm; hll = hl;
+        }
+        if (H[M] > cmax) { cmax = H[M]; cfirst = i; cm = HM[M]; cl = HL[M]; }
+    }
+    int32_t score = QO_NEG, end_q = L - 1, end_r = 0, mm = 0, ll = 0;
+    for (int j = 1; j <= M; ++j)
+        if (H[j] > score) { score = H[j]; end_r = j - 1; end_q = L - 1; mm = HM[j]; ll = HL[j]; }
+    if (cmax > score || (cmax == score && end_r == M - 1)) { score = cmax; end_r = M - 1; end_q = cfirst - 1; mm = cm; ll = cl; }
+    out->score = score; out->end_query = end_q; out->end_ref = end_r; out->matches = mm; out->length = ll;
     return 0;
 }
 

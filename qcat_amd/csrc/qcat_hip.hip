@@ -1339,6 +1339,39 @@ extern "C" int qcat_scan_sequences(qcat_ctx* c, const qcat_kit* ckit, const uint
     return rc;
 }
 
+extern "C" int qcat_sg_align(qcat_ctx* c, const uint8_t* queries, const uint64_t* q_offsets, const uint8_t* targets,
+                             const uint64_t* t_offsets, uint32_t n, int32_t gap_open, int32_t gap_extend, const int8_t* matrix,
+                             int32_t with_stats, qcat_alignment* out) {
+    if (!c || !q_offsets || !t_offsets || !matrix || !out) return set_err(QCAT_ERR_ARG, "qcat_sg_align: null argument");
+    if (n == 0) return 0;
+    if (gap_open < 0 || gap_extend < 0) return set_err(QCAT_ERR_ARG, "qcat_sg_align: negative gap cost");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (q_offsets[i + 1] < q_offsets[i] || t_offsets[i + 1] < t_offsets[i]) return set_err(QCAT_ERR_ARG, "offsets must be non-decreasing");
+        if (t_offsets[i + 1] - t_offsets[i] > (uint64_t)MAX_TLEN) return set_err(QCAT_ERR_UNSUPPORTED, "qcat_sg_align: target longer than QCAT_MAX_TEMPLATE_LEN");
+        if (q_offsets[i + 1] - q_offsets[i] >= (1ull << 31)) return set_err(QCAT_ERR_UNSUPPORTED, "qcat_sg_align: query longer than 2^31 - 1");
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t qb = q_offsets[n], tb = t_offsets[n];
+    if ((qb && !queries) || (tb && !targets)) return set_err(QCAT_ERR_ARG, "qcat_sg_align: null sequence buffer");
+    const uint32_t blocks = (n + GEN_THREADS - 1) / GEN_THREADS;
+    const size_t threads = (size_t)blocks * GEN_THREADS;
+    DevTemp dq, dqo, dt, dto, dscr, dout;
+    HIPCHK(dq.alloc(qb + 1)); HIPCHK(dqo.alloc(((size_t)n + 1) * 8)); HIPCHK(dt.alloc(tb + 1)); HIPCHK(dto.alloc(((size_t)n + 1) * 8));
+    HIPCHK(dscr.alloc((with_stats ? 6 : 2) * (size_t)(MAX_TLEN + 1) * threads * 4)); HIPCHK(dout.alloc((size_t)n * sizeof(qcat_alignment)));
+    if (qb) HIPCHK(hipMemcpyAsync(dq.p, queries, qb, hipMemcpyHostToDevice, c->stream));
+    if (tb) HIPCHK(hipMemcpyAsync(dt.p, targets, tb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dqo.p, q_offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dto.p, t_offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    SgMatrix m;
+    memcpy(m.m, matrix, 49);
+    hipLaunchKernelGGL(k_sg_align, dim3(blocks), dim3(GEN_THREADS), 0, c->stream, dq.as<uint8_t>(), dqo.as<uint64_t>(), dt.as<uint8_t>(),
+                       dto.as<uint64_t>(), n, (int)gap_open, (int)gap_extend, m, with_stats ? 1 : 0, dscr.as<int32_t>(), dout.as<qcat_alignment>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * sizeof(qcat_alignment), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // native FASTQ ingest and egress
 // ------------------------------------------------------------------------------------------

@@ -286,6 +286,7 @@ class HipLibrary(object):
             "qcat_ctx_results_devptr": (vp, [vp]),
             "qcat_ctx_last_timing": (C.c_int, [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]),
             "qcat_ctx_set_timing": (C.c_int, [vp, C.c_int]),
+            "qcat_sg_align": (C.c_int, [vp, vp, vp, vp, vp, u32, i32, i32, vp, i32, vp]),
             "qcat_fastq_open": (C.c_int, [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
             "qcat_fastq_close": (None, [vp]),
             "qcat_fastq_read_info": (C.c_int, [vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(u32), C.POINTER(C.c_uint64), C.POINTER(u32)]),
@@ -520,6 +521,25 @@ class NativeContext(object):
             out.ctypes.data, cptr, traces.ctypes.data,
             bc_rows.ctypes.data if bc_rows is not None else None, stride))
         return out, traces, bc_rows
+
+
+ALIGN_DTYPE = np.dtype([("score", "<i4"), ("end_query", "<i4"), ("end_ref", "<i4"), ("matches", "<i4"), ("length", "<i4")])
+
+
+def sg_align(ctx, queries, targets, gap_open, gap_extend, table, with_stats=False):
+    """qcat_sg_align: semi-global alignments of queries[i] against targets[i] on the device (parasail_sg /
+    parasail_sg_stat of the reference's helpers); returns an ALIGN_DTYPE array."""
+    n = len(queries)
+    out = np.zeros(n, dtype=ALIGN_DTYPE)
+    if n == 0:
+        return out
+    qb, qo = pack_reads(queries)
+    tb, to = pack_reads(targets)
+    t = np.ascontiguousarray(np.asarray(table, dtype=np.int8).reshape(-1))
+    hip = HipLibrary.get()
+    hip.check(hip.lib.qcat_sg_align(ctx.handle, qb.ctypes.data, qo.ctypes.data, tb.ctypes.data, to.ctypes.data, n,
+                                    int(gap_open), int(gap_extend), t.ctypes.data, 1 if with_stats else 0, out.ctypes.data))
+    return out
 
 
 class FastqFile(object):

@@ -44,6 +44,132 @@ def extract_align_sequence(read_sequence, rev_comp, length):
     return seq
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's module-level helpers (``qcat/scanner_base.py:29-359``) with their signatures and return values, for
+# callers that use them directly (``qcat/test/test_barcode.py:291-304`` calls ``find_best_adapter_template``; the eval
+# tools call ``eval_adapter_template``).  The scanners above never go through them -- a batch is one native call -- but
+# every alignment here runs on the device as well (``qcat_sg_align``, include/qcat_hip.h): there is no CPU path.
+# ---------------------------------------------------------------------------------------------------------------
+class Alignment(object):
+    """What the helpers hand out where the reference hands out a parasail ``Result``: ``score``, ``end_query``,
+    ``end_ref``, and from the ``_stat`` form ``matches`` / ``length``."""
+    __slots__ = ("score", "end_query", "end_ref", "matches", "length")
+
+    def __init__(self, rec):
+        self.score, self.end_query, self.end_ref = int(rec["score"]), int(rec["end_query"]), int(rec["end_ref"])
+        self.matches, self.length = int(rec["matches"]), int(rec["length"])
+
+
+_helper_ctx = {}
+
+
+def _ctx(device=0):
+    if device not in _helper_ctx:
+        _helper_ctx[device] = native.NativeContext(device)
+    return _helper_ctx[device]
+
+
+def _sg(queries, targets, gap_open, gap_extend, matrix, with_stats=False):
+    return native.sg_align(_ctx(), queries, targets, gap_open, gap_extend, matrix.table, with_stats=with_stats)
+
+
+def extract_barcode_region(read_sequence, adapter_template, barcode_set_index, alignment_stop_ref, qcat_config):
+    """``qcat/scanner_base.py:29-60``: the slice of the window the barcode of the aligned adapter lies in, widened by
+    ``extracted_barcode_extension`` on both sides (Python slice semantics, negative indices wrap)."""
+    barcode_end = adapter_template.get_barcode_end(barcode_set_index)
+    barcode_length = adapter_template.get_barcode_length(barcode_set_index)
+    end_ref = alignment_stop_ref - (adapter_template.get_adapter_length() - barcode_end) + 1
+    start_ref = end_ref - barcode_length
+    start_ref -= min(qcat_config.extracted_barcode_extension, start_ref)
+    end_ref += min(qcat_config.extracted_barcode_extension, len(read_sequence) - end_ref)
+    return read_sequence[start_ref:end_ref + 1]
+
+
+def find_highest_scoring_barcode(barcode_region_read, barcode_set, qcat_config, upstream_context="",
+                                 downstream_context="", compute_identity=False):
+    """``qcat/scanner_base.py:63-141``: every barcode of the list (with its contexts) aligned to the region, the
+    highest normalised score wins with the reference's ``not max_score`` replacement rule; returns
+    ``(barcode, score, score, end_query)`` -- the reference returns the score in the identity slot too (``:141``)."""
+    max_barcode, q_score, max_identity, max_end = None, 0, 0.0, -1
+    if not barcode_region_read:
+        return max_barcode, q_score, max_identity, max_end
+    targets = [upstream_context + b.sequence + downstream_context for b in barcode_set]
+    al = _sg([barcode_region_read] * len(targets), targets, 1, 1, qcat_config.matrix_barcode, with_stats=compute_identity)
+    max_score = None
+    for b, target, a in zip(barcode_set, targets, al):
+        score = int(a["score"]) * 100.0 / (1.0 * len(target))
+        if not max_score or max_score < score:
+            max_score, max_barcode, max_end = score, b, int(a["end_query"])
+    return max_barcode, max_score, max_score, max_end
+
+
+def align_adapter_identity(adapter_sequence, adapter_length, read_sequence, barcode_length, qcat_config):
+    """``qcat/scanner_base.py:144-188``: the adapter alignment with its identity = matches / (alignment columns - barcode
+    length); an alignment that covers less than 85 % of the adapter is discarded ``(None, 0.0)``.  ``matches`` / ``length``
+    follow one optimal path (include/qcat_hip.h, qcat_sg_align: parity with parasail's choice among several optimal paths
+    is unpinned)."""
+    if not read_sequence or not adapter_sequence:
+        return None, 0.0
+    a = Alignment(_sg([read_sequence], [adapter_sequence], qcat_config.gap_open, qcat_config.gap_extend, qcat_config.matrix,
+                      with_stats=True)[0])
+    if a.length < (adapter_length * 0.85):
+        return None, 0.0
+    return a, float(a.matches) / float(a.length - barcode_length)
+
+
+def align_adapter(adapter_sequence, read_sequence, qcat_config):
+    """``qcat/scanner_base.py:191-220``."""
+    if not read_sequence or not adapter_sequence:
+        return None, 0.0
+    return Alignment(_sg([read_sequence], [adapter_sequence], qcat_config.gap_open, qcat_config.gap_extend, qcat_config.matrix)[0]), 0.0
+
+
+def compute_adapter_identity(adapter_template, read_sequence, qcat_config):
+    """``qcat/scanner_base.py:247-255``."""
+    return align_adapter_identity(adapter_template.get_adapter_sequences(), adapter_template.get_adapter_length(), read_sequence,
+                                  adapter_template.get_barcode_length(0) + adapter_template.get_barcode_length(1), qcat_config)[1]
+
+
+def eval_adapter_template(adapter_template, read_sequence, qcat_config, identity=True):
+    """``qcat/scanner_base.py:258-296``: (end_query, identity, raw score) of one template; (-1, 0.0, -1) without an
+    alignment."""
+    if identity:
+        aligned, ident = align_adapter_identity(adapter_template.get_adapter_sequences(), adapter_template.get_adapter_length(),
+                                                read_sequence,
+                                                adapter_template.get_barcode_length(0) + adapter_template.get_barcode_length(1),
+                                                qcat_config)
+    else:
+        aligned, ident = align_adapter(adapter_template.get_adapter_sequences(), read_sequence, qcat_config)
+    if aligned is None:
+        return -1, ident, -1
+    return aligned.end_query, ident, aligned.score
+
+
+def get_norm_socre(template, score, qcat_config):
+    """``qcat/scanner_base.py:299-310`` (the reference's spelling)."""
+    bc_len = template.get_barcode_length(0) + template.get_barcode_length(1)
+    a_len = template.get_adapter_length()
+    return score * 100.0 / ((a_len - bc_len) * qcat_config.match + bc_len * qcat_config.nmatch)
+
+
+def find_best_adapter_template(adapter_templates, read_sequence, qcat_config):
+    """``qcat/scanner_base.py:313-359``: (index, end_query, normalised score) of the best template, the first one on
+    ties; (-1, -1, -1.0) for empty inputs.  All templates are aligned in one device call."""
+    best_score, best_end, best_tpl = -1.0, -1, -1
+    if not adapter_templates or not read_sequence:
+        return best_tpl, best_end, best_score
+    if not isinstance(adapter_templates, list):
+        adapter_templates = [adapter_templates]
+    idx = [i for i, t in enumerate(adapter_templates) if t.get_adapter_sequences()]
+    al = _sg([read_sequence] * len(idx), [adapter_templates[i].get_adapter_sequences() for i in idx],
+             qcat_config.gap_open, qcat_config.gap_extend, qcat_config.matrix)
+    for i, a in zip(idx, al):
+        score = get_norm_socre(adapter_templates[i], int(a["score"]), qcat_config)
+        if best_score < score:
+            best_score, best_tpl, best_end = score, i, int(a["end_query"])
+    return best_tpl, best_end, best_score
+
+
 class BarcodeScanner(object):
     """Abstract base class of the MI355X scanners (mirror of ``qcat.scanner_base.BarcodeScanner``)."""
 

@@ -49,6 +49,21 @@ def sg(s1, s2, open_, extend, table):
     return sc.value, eq.value, er.value
 
 
+class _Stats(C.Structure):
+    _fields_ = [("score", C.c_int32), ("end_query", C.c_int32), ("end_ref", C.c_int32), ("matches", C.c_int32), ("length", C.c_int32)]
+
+
+def sg_stats(s1, s2, open_, extend, table):
+    """(score, end_query, end_ref, matches, length) of the oracle DP with statistics (qo_sg_stats)."""
+    t = np.ascontiguousarray(table, dtype=np.int8)
+    st = _Stats()
+    b1, b2 = s1.encode("latin-1", "replace"), s2.encode("latin-1", "replace")
+    fn = lib().qo_sg_stats
+    fn.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_Stats)]
+    _check(fn(b1, len(b1), b2, len(b2), open_, extend, t.ctypes.data, C.byref(st)))
+    return st.score, st.end_query, st.end_ref, st.matches, st.length
+
+
 def scan(descriptor, reads=None, packed=None, counts=False, trace=False, rows=False, threads=1):
     """Run the oracle over a batch.  ``descriptor`` is a native.KitDescriptor."""
     bases, offsets = packed if packed is not None else native.pack_reads(reads)

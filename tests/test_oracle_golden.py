@@ -151,3 +151,33 @@ def test_simple_mode(i):
     recs = oracle_lib.scan(det.descriptor(), reads)
     assert [helpers.simple_record_as_golden(r, det.barcodes) for r in recs] == entry["results"]
     assert sum(1 for r in entry["results"] if r["barcode_name"]) > len(reads) // 2
+
+
+def test_dp_statistics_against_the_independent_dp():
+    """qo_sg_stats (matches / alignment length along one optimal path, oracle/qcat_oracle.c) against the independent
+    scalar DP's sg_stats on seeded pairs: same score / end position as qo_sg, same tie order for the two statistics
+    (parity with parasail's own choice of path is unpinned -- nothing on a scanner path consumes them)."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(helpers.GOLDEN))
+    import sg_independent as si
+    from qcat_amd import config as qconfig
+    cfg = qconfig.qcatConfig()
+    rng = random.Random(20260929)
+    for matrix in (cfg.matrix, cfg.matrix_barcode):
+        tab = matrix.table
+        alpha = "ATGCNX"
+
+        def score(a, b, tab=tab):
+            ia, ib = alpha.find(a.upper()), alpha.find(b.upper())
+            return int(tab[ib if ib >= 0 else 6][ia if ia >= 0 else 6])
+        for _ in range(150):
+            L, M = rng.randrange(1, 90), rng.randrange(1, 50)
+            s1 = "".join(rng.choice("ACGT" if rng.random() < 0.9 else "ACGTNRacgt") for _ in range(L))
+            s2 = "".join(rng.choice("ACGTN") for _ in range(M))
+            if rng.random() < 0.5 and L > M:
+                p = rng.randrange(0, L - M + 1)
+                s1 = s1[:p] + "".join(c if (c != "N" and rng.random() > 0.1) else rng.choice("ACGT") for c in s2) + s1[p + M:]
+            go, ge = rng.choice([(2, 2), (1, 1), (3, 1), (5, 2)])
+            assert tuple(si.sg_stats(s1, s2, go, ge, score)) == oracle_lib.sg_stats(s1, s2, go, ge, tab), (s1, s2, go, ge)
+            assert oracle_lib.sg_stats(s1, s2, go, ge, tab)[:3] == oracle_lib.sg(s1, s2, go, ge, tab)
