@@ -213,7 +213,7 @@ def main():
         compute = {k: v for k, v in avg.items() if not k.startswith("rccl")}
         dom = max(compute, key=compute.get) if compute else None
         traffic = traffic_src = None
-        for tname in ("r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", tname)) as fh:
                     tj = json.load(fh).get("config3" if a.workload == "config4" else a.workload)
@@ -232,15 +232,16 @@ def main():
                     "algorithmic_bytes_per_launch": a.reads * bytes_per_read,
                     "avg_launch_ms": round(avg[dom], 4),
                     "kernels_avg_ms": {k: round(v, 4) for k, v in avg.items()},
-                    "note": "integer DP (bit-sliced boolean planes for the barcode scan, exact-integer fp16 / u16 lanes for the rest): "
+                    "note": "integer DP (bit-sliced boolean planes for the barcode scan and, in big batches, the adapter scan; exact-integer fp16 / u16 lanes for the rest): "
                             "VALU-issue bound, not HBM bound (SURVEY.md 8d); see valu_issue"}
         out = {"metric": "reads/sec demultiplexed", "value": round(value, 1), "unit": "reads/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
-               "dtype": "int16 / bit planes (the reference's int32 DP as differences of neighbouring cells in two boolean planes "
-                        "for the barcode scan, in 16-bit lanes -- u16 / exact-integer f16 -- for the adapter scan; both proven exact "
-                        "per kit by range bounds at kit creation; kits outside the bounds run the int32 kernel)",
+               "dtype": "bit planes / int16 (the reference's int32 DP as differences of neighbouring cells in boolean planes: two per "
+                        "difference for the barcode scan, four for the adapter scan of big batches; 16-bit lanes -- u16 / exact-integer "
+                        "f16 -- for the rest; all proven exact per kit by range bounds at kit creation; kits outside the bounds run "
+                        "the int32 kernel)",
                "data": "synthetic",
                "config": {"workload": "%s: %d synthetic reads/GPU, kit %s (%s), %s, error rate %.2f, "
                                       "~%d nt reads" % (a.workload, a.reads, kit_name or "DUAL", mode,

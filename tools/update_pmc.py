@@ -18,10 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # kernel-name fragments -> the timing mark their launches are enclosed by (packed_host.inc / qcat_hip.hip)
 MARKS = [
     ("k_pack_windows", "k_pack_windows"),
+    ("k_adapter_finish", "k_job_sort"),                 # (launched after the adapter phase's mark: its time is in the next one)
     ("k_abs_", "k_adapter_static"), ("k_adapter_bs", "k_adapter_static"),
     ("k_adapter_fused2", "k_adapter_static"), ("k_adapter_static", "k_adapter_static"),
     ("k_adapter_packed", "k_adapter_packed"),
-    ("k_adapter_finish", "k_adapter_static"),
     ("k_job_", "k_job_sort"),
     ("k_bs_", "k_barcode_bitslice"),
     ("k_barcode_static", "k_barcode_static"), ("k_barcode_packed", "k_barcode_packed"),
