@@ -10,7 +10,7 @@
 // FOUR bit planes each, and a cell is
 //       m = max(W', a(i,j-1), b(i-1,j));     a(i,j) = m - b(i-1,j);     b(i,j) = m - a(i,j-1).
 // Bit-slicing ACROSS ALIGNMENTS (bit k of a quantity of 32 alignments per 32-bit word, 64 lanes: 2048 alignments per
-// wave instruction) turns that into 27 three-input boolean instructions for a letter column and 25 for an N column
+// wave instruction) turns that into 24 three-input boolean instructions per column (27 / 25 in the hand-made reference form, 24 / 24 after the search)
 // (v_bitop3_b32, any function of three registers), where the packed-binary16 form (kernels_static.inc) spends two
 // half-rate packed instructions per 128 cells.
 //
@@ -87,10 +87,12 @@ ABS_FN void abs_sub(const u32 (&m)[ABS_NP], const u32 (&s)[ABS_NP], u32 (&d)[ABS
     d[3] = AB3(m[3], s[3], c2, x ^ y ^ z);
 }
 
-// one cell of a LETTER column.  neq: mismatch mask of the alignments' query letter against the column's letter;
-// a: difference down the column to the left (in) -> of this column (out); b: difference along the row above (in) ->
-// of this row (out).  m = neq ? max(a, b, 2) : 9.   27 instructions.
-ABS_FN void abs_cell_letter(u32 neq, u32 (&a)[ABS_NP], u32 (&b)[ABS_NP]) {
+// one cell of a LETTER column, reference form.  neq: mismatch mask of the alignments' query letter against the column's
+// letter; a: difference down the column to the left (in) -> of this column (out); b: difference along the row above (in)
+// -> of this row (out).  m = neq ? max(a, b, 2) : 9.   27 instructions: the hand-made network the search started from
+// (tools/lut3_search_adapter.cpp) and what the searched networks below are checked against, exhaustively
+// (tests/abs_host_check.cpp).
+ABS_FN void abs_cell_letter_ref(u32 neq, u32 (&a)[ABS_NP], u32 (&b)[ABS_NP]) {
     u32 mx[ABS_NP], m[ABS_NP], na[ABS_NP], nb[ABS_NP];
     abs_max(a, b, mx);
     const u32 z = AB3(mx[3], mx[2], mx[1], x | y | z);           // max(a, b) >= 2
@@ -104,8 +106,8 @@ ABS_FN void abs_cell_letter(u32 neq, u32 (&a)[ABS_NP], u32 (&b)[ABS_NP]) {
     for (int k = 0; k < ABS_NP; ++k) { a[k] = na[k]; b[k] = nb[k]; }
 }
 
-// one cell of an N column (every query letter scores -1 against a template N): m = max(a, b, 3).  25 instructions.
-ABS_FN void abs_cell_n(u32 (&a)[ABS_NP], u32 (&b)[ABS_NP]) {
+// one cell of an N column (every query letter scores -1 against a template N), reference form: m = max(a, b, 3).  25.
+ABS_FN void abs_cell_n_ref(u32 (&a)[ABS_NP], u32 (&b)[ABS_NP]) {
     u32 mx[ABS_NP], m[ABS_NP], na[ABS_NP], nb[ABS_NP];
     abs_max(a, b, mx);
     const u32 z = mx[3] | mx[2];                                   // max(a, b) >= 4
@@ -116,6 +118,69 @@ ABS_FN void abs_cell_n(u32 (&a)[ABS_NP], u32 (&b)[ABS_NP]) {
     abs_sub(m, a, nb);
 #pragma unroll
     for (int k = 0; k < ABS_NP; ++k) { a[k] = na[k]; b[k] = nb[k]; }
+}
+
+// The cells the kernels run: networks found by tools/lut3_search_adapter.cpp from the reference forms above (a node is
+// deleted, fan-ins and truth tables are re-annealed until all eight outputs are exact again on every valid input: a, b in
+// 0..9 -- values above 9 never occur, which is what the smaller networks exploit), pasted by tools/lut3_to_cpp.py.
+ABS_FN void abs_cell_letter(u32 neq, u32 (&a)[ABS_NP], u32 (&b)[ABS_NP]) {
+    // EXACT=1 letter cell, 24 nodes; signals 0..3 = a3..a0, 4..7 = b3..b0, 8 = neq; outputs a'3..a'0 b'3..b'0 = s25 s24 s22 s20 s32 s30 s28 s26
+    const u32 s9 = ABS_LUT(a[1], b[1], b[0], 0x8e);
+    const u32 s10 = ABS_LUT(a[2], b[2], s9, 0x8e);
+    const u32 s11 = ABS_LUT(a[3], b[3], s10, 0x8e);
+    const u32 s12 = ABS_LUT(b[3], neq, a[3], 0xfb);
+    const u32 s13 = ABS_LUT(b[2], s12, a[2], 0x32);
+    const u32 s14 = ABS_LUT(s10, b[1], a[1], 0xca);
+    const u32 s15 = ABS_LUT(s11, b[0], a[0], 0xca);
+    const u32 s16 = ABS_LUT(s12, s13, s14, 0x7e);
+    const u32 s17 = ABS_LUT(s12, b[2], b[2], 0x34);
+    const u32 s18 = ABS_LUT(s12, s14, s13, 0x2d);
+    const u32 s19 = ABS_LUT(neq, s15, s16, 0x8b);
+    const u32 s20 = ABS_LUT(s9, s19, b[0], 0x66);
+    const u32 s21 = ABS_LUT(b[0], s19, b[0], 0x70);
+    const u32 s22 = ABS_LUT(s18, b[1], s21, 0x96);
+    const u32 s23 = ABS_LUT(s22, s21, b[1], 0xe8);
+    const u32 s24 = ABS_LUT(s13, b[2], s23, 0x16);
+    const u32 s25 = ABS_LUT(b[3], s23, s17, 0xc2);
+    const u32 s26 = ABS_LUT(neq, s19, a[0], 0x64);
+    const u32 s27 = ABS_LUT(s26, a[0], a[3], 0x40);
+    const u32 s28 = ABS_LUT(s18, a[1], s27, 0x96);
+    const u32 s29 = ABS_LUT(s28, a[1], s18, 0xd4);
+    const u32 s30 = ABS_LUT(s13, a[2], s29, 0x96);
+    const u32 s31 = ABS_LUT(s29, a[3], s12, 0x3d);
+    const u32 s32 = ABS_LUT(s31, s30, b[3], 0x03);
+    a[3] = s25; a[2] = s24; a[1] = s22; a[0] = s20;
+    b[3] = s32; b[2] = s30; b[1] = s28; b[0] = s26;
+}
+
+ABS_FN void abs_cell_n(u32 (&a)[ABS_NP], u32 (&b)[ABS_NP]) {
+    // EXACT=1 N cell, 24 nodes; signals 0..3 = a3..a0, 4..7 = b3..b0; outputs a'3..a'0 b'3..b'0 = s24 s22 s20 s18 s31 s29 s27 s25
+    const u32 s8 = ABS_LUT(a[1], b[1], b[0], 0x8e);
+    const u32 s9 = ABS_LUT(a[2], b[2], s8, 0x8e);
+    const u32 s10 = ABS_LUT(a[3], b[3], s9, 0x8e);
+    const u32 s11 = ABS_LUT(s10, b[3], a[3], 0xca);
+    const u32 s12 = ABS_LUT(s10, b[2], a[2], 0xca);
+    const u32 s13 = ABS_LUT(s10, b[1], a[1], 0xca);
+    const u32 s14 = ABS_LUT(s10, b[0], a[0], 0xca);
+    const u32 s15 = ABS_LUT(s11, s12, s12, 0xfc);
+    const u32 s16 = ABS_LUT(s13, s15, s15, 0xf3);
+    const u32 s17 = ABS_LUT(s14, s15, s15, 0xf3);
+    const u32 s18 = ABS_LUT(s17, b[0], b[0], 0x3c);
+    const u32 s19 = ABS_LUT(s17, b[0], b[0], 0x0c);
+    const u32 s20 = ABS_LUT(s16, b[1], s19, 0x96);
+    const u32 s21 = ABS_LUT(s16, b[1], s19, 0x8e);
+    const u32 s22 = ABS_LUT(s12, b[2], s21, 0x96);
+    const u32 s23 = ABS_LUT(s12, b[2], s21, 0x8e);
+    const u32 s24 = ABS_LUT(s11, b[3], s23, 0x96);
+    const u32 s25 = ABS_LUT(s17, a[0], a[0], 0x3c);
+    const u32 s26 = ABS_LUT(s17, a[0], a[0], 0x0c);
+    const u32 s27 = ABS_LUT(s16, a[1], s26, 0x96);
+    const u32 s28 = ABS_LUT(s16, a[1], s26, 0x8e);
+    const u32 s29 = ABS_LUT(s12, a[2], s28, 0x96);
+    const u32 s30 = ABS_LUT(s12, a[2], s28, 0x8e);
+    const u32 s31 = ABS_LUT(s11, a[3], s30, 0x96);
+    a[3] = s24; a[2] = s22; a[1] = s20; a[0] = s18;
+    b[3] = s31; b[2] = s29; b[1] = s27; b[0] = s25;
 }
 
 // mismatch masks of a row against the four letters (codes A, T, G, C = 0..3 in planes c1 c0)

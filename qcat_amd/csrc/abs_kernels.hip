@@ -18,6 +18,19 @@ extern "C" void qcat_abs_launch_planes(unsigned n_tiles, void* stream, const uin
                            static_cast<uint2*>(planes), valid, need128, tile_any);
 }
 
+// the same with the windows packed in the same pass (k_pack_planes): reads -> win / wlen / wspec AND planes / valid / flags
+extern "C" void qcat_abs_launch_pack_planes(unsigned n_tiles, void* stream, const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads, int ends,
+                                            uint8_t* win, int32_t* wlen, uint8_t* wspec, uint32_t n_ends, int rows, void* planes, uint32_t* valid,
+                                            uint8_t* need128, uint32_t* tile_any) {
+    const qk::AbsPackSrc ps{bases, offsets, n_reads, ends};
+    if (rows == 150)
+        hipLaunchKernelGGL(qk::k_pack_planes<150>, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), ps, win, wlen, wspec, n_ends, rows,
+                           static_cast<uint2*>(planes), valid, need128, tile_any);
+    else
+        hipLaunchKernelGGL(qk::k_pack_planes<0>, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), ps, win, wlen, wspec, n_ends, rows,
+                           static_cast<uint2*>(planes), valid, need128, tile_any);
+}
+
 // kind 0: fused two-template plan `id` (g_static_fused), kind 1: single-template plan `id` (g_static_templates); returns 0
 // when the plan does not exist (the caller keeps the binary16 kernel)
 extern "C" int qcat_abs_launch(int kind, int id, unsigned grid, void* stream, const void* args) {

@@ -598,15 +598,30 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
 
     KitPtrs kp{kd->kit, kd->codes, kd->ids, kd->tables};
     g_jit = kd;
+    const bool use_packed = hk.fast_ok && !c->force_generic && packed_supported(hk);
     if (resume_kit_mask < 0) {
         uint64_t threads = (uint64_t)n_ends * (WIN_STRIDE / 16);
         uint32_t blocks = (uint32_t)((threads + 255) / 256);
         HIPCHK(hipMemsetAsync(c->wspec, 0, n_ends, c->stream));
-        hipLaunchKernelGGL(k_pack_windows, dim3(blocks), dim3(256), 0, c->stream,
-                           b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen, c->wspec);
+        c->packed.abs_ready = 0;
+        if (use_packed && hk.mode != QCAT_MODE_SIMPLE && getenv("QCAT_HIP_PACK_PLANES") != nullptr && packed_abs_wanted(hk, (uint32_t)n_ends, true)) {
+            // (A/B switch, off by default) the windows and their letter planes in one pass (kernels_abs.inc: k_pack_planes).
+            // Measured and dropped: 5.1 ms against 1.67 + 0.85 ms for k_pack_windows + k_abs_planes on config 3 -- a wave that
+            // walks eight slices of 640 items serially is latency-bound on the offsets -> bases load chains, where
+            // k_pack_windows has one thread per item (profiles/r03_ab_pack_planes.json)
+            if ((rc = packed_abs_buffers(c->stream, hk, (uint32_t)n_ends, &c->packed))) return set_err(rc, packed_last_error());
+            const uint32_t tiles = ((uint32_t)n_ends + ABS_TILE - 1) / ABS_TILE;
+            uint32_t* cursor = reinterpret_cast<uint32_t*>(c->packed.abs_flags);
+            uint32_t* tile_any = cursor + MAX_T;
+            qcat_abs_launch_pack_planes(tiles, c->stream, b->bases, b->offsets, n, ends, c->win, c->wlen, c->wspec, (uint32_t)n_ends, hk.max_align,
+                                        c->packed.abs_planes, c->packed.abs_valid, reinterpret_cast<uint8_t*>(tile_any + tiles), tile_any);
+            c->packed.abs_ready = (uint32_t)n_ends;
+        } else {
+            hipLaunchKernelGGL(k_pack_windows, dim3(blocks), dim3(256), 0, c->stream,
+                               b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen, c->wspec);
+        }
         mark(c, "k_pack_windows");
     }
-    const bool use_packed = hk.fast_ok && !c->force_generic && packed_supported(hk);
     if (hk.mode == QCAT_MODE_SIMPLE && adapter_only) return set_err(QCAT_ERR_ARG, "simple mode has no adapter templates to vote with");
     if (resume_kit_mask >= 0 && !(use_packed && c->packed.slices_single))
         return set_err(QCAT_ERR_UNSUPPORTED, "the adapter pass of this kit cannot be resumed per kit (table or general kernels)");

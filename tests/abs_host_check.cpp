@@ -123,12 +123,42 @@ static int check_plan(const char* name, const std::string* tpls, int rounds, int
     return bad;
 }
 
+// the searched cell networks against the reference forms, on every valid input (a, b in 0..9, both letter outcomes)
+static int check_cells() {
+    int bad = 0;
+    for (int neq = 0; neq < 2; ++neq) {
+        u32 a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+        // bit (av * 3 + bv / 4 ...) -- simply one (a, b) pair per bit, 100 pairs over four words' worth of passes
+        for (int base = 0; base < 100; base += 32) {
+            for (int k = 0; k < 4; ++k) a[k] = b[k] = 0;
+            for (int bit = 0; bit < 32 && base + bit < 100; ++bit) {
+                const int av = (base + bit) / 10, bv = (base + bit) % 10;
+                for (int k = 0; k < 4; ++k) { a[k] |= (u32)((av >> k) & 1) << bit; b[k] |= (u32)((bv >> k) & 1) << bit; }
+            }
+            const u32 live = base + 32 <= 100 ? 0xFFFFFFFFu : ((1u << (100 - base)) - 1u);
+            u32 a1[4], b1[4], a2[4], b2[4];
+            for (int k = 0; k < 4; ++k) { a1[k] = a2[k] = a[k]; b1[k] = b2[k] = b[k]; }
+            abs_cell_letter_ref(neq ? 0xFFFFFFFFu : 0u, a1, b1);
+            abs_cell_letter(neq ? 0xFFFFFFFFu : 0u, a2, b2);
+            for (int k = 0; k < 4; ++k) bad += ((a1[k] ^ a2[k]) & live) != 0 || ((b1[k] ^ b2[k]) & live) != 0;
+            if (neq) {
+                for (int k = 0; k < 4; ++k) { a1[k] = a2[k] = a[k]; b1[k] = b2[k] = b[k]; }
+                abs_cell_n_ref(a1, b1);
+                abs_cell_n(a2, b2);
+                for (int k = 0; k < 4; ++k) bad += ((a1[k] ^ a2[k]) & live) != 0 || ((b1[k] ^ b2[k]) & live) != 0;
+            }
+        }
+    }
+    printf("cells: searched networks against the reference forms on all valid inputs: %d mismatches\n", bad);
+    return bad;
+}
+
 struct Seqs { const char* a; const char* b; };
 
 int main(int argc, char** argv) {
     g_s = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
     const int rounds = argc > 2 ? atoi(argv[2]) : 20;
-    int bad = 0;
+    int bad = check_cells();
 #include "abs_host_cases.inc"
     return bad ? 1 : 0;
 }

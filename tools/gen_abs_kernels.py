@@ -26,10 +26,10 @@ import gen_static_kernels as gsk  # noqa: E402
 OUT = os.path.join(ROOT, "qcat_amd", "csrc", "abs_generated.inc")
 CASES_OUT = os.path.join(ROOT, "tests", "abs_host_cases.inc")
 LETTER = {"A": 0, "T": 1, "G": 2, "C": 3}          # qcat_amd/codes.py: the plane code of a letter
-# instructions per row as compiled (profiles/r03_*): cells 27 / 25, a border step with its index latch 46, a hand-over
+# instructions per row as compiled (profiles/r03_*): cells 24 / 24 (the searched networks of abs_core.h), a border step with its index latch 46, a hand-over
 # set 5 LDS instructions on either side; stage 1 also pays the row's LDS reads, masks and loop overhead (+30)
-COST = {"L": 27, "N": 25, "border": 46, "handover": 5, "stage1": 30}
-MAX_STAGE_COLUMNS = 46                              # 4 planes per column + ~60 working registers <= 256 VGPRs (two waves per SIMD)
+COST = {"L": 24, "N": 24, "border": 46, "handover": 5, "stage1": 30}
+MAX_STAGE_COLUMNS = 52                              # 4 planes per column + ~60 working registers <= 256 VGPRs (two waves per SIMD)
 
 
 def program(seqs):

@@ -7,7 +7,8 @@
 // of its inputs) and anneals fan-ins and truth tables at a low temperature until the outputs are exact again on all
 // valid input patterns (a, b <= 9), then goes on from the smaller network.  Every exact network found is printed.
 // build: g++ -O2 -std=c++17 -pthread tools/lut3_search_adapter.cpp -o /tmp/lut3a
-// usage: /tmp/lut3a <letter|n> [threads] [iterations per attempt]     (runs until killed; wrap in `timeout`)
+// usage: /tmp/lut3a <letter|n> [threads] [iterations per attempt] [log of an earlier run to continue from] [seed]
+//        (runs until killed; wrap in `timeout`)
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -19,13 +20,14 @@
 #include <thread>
 #include <vector>
 
-constexpr int NW = 16;                                  // 512 patterns: pattern = a << 5 | b << 1 | neq
+constexpr int NW = 32;                                  // up to 1024 patterns (adapter cells use the first 512: a << 5 | b << 1 | neq)
 struct Sig { uint32_t w[NW]; };
 struct Node { int f[3]; uint8_t tab; };
 struct Net { std::vector<Node> nodes; };
 
 static int g_nin = 9;                                   // 9 inputs (letter cell) or 8 (N cell: neq ignored)
-static Sig g_in[9], g_valid, g_target[8];
+static Sig g_in[10], g_valid, g_target[8];
+static int g_mode = 0;                                  // 0 letter cell, 1 N cell, 2 the barcode kernels' deficit step
 static std::mutex g_mu;
 
 static inline void eval_node(const Sig* s, const Node& n, Sig& out) {
@@ -55,6 +57,24 @@ static int cost(const Net& n, std::vector<Sig>& s, int* out_nodes = nullptr) {
         total += best;
     }
     return total;
+}
+
+// mode 2: bs_deficit of kernels_bitslice.inc -- F (8 planes, 0..151: 1 + deficit of the last column, 0 before the first
+// row) and a (2 planes, dv + 1 in 0..3) -> F' = max(F + 1 - a, 1).  signals: 0..7 = f0..f7, 8 = a1, 9 = a0.
+static void setup_deficit() {
+    g_nin = 10;
+    memset(g_in, 0, sizeof g_in); memset(&g_valid, 0, sizeof g_valid); memset(g_target, 0, sizeof g_target);
+    for (int p = 0; p < 1024; ++p) {
+        const int F = p >> 2, a = p & 3;
+        auto set = [&](Sig& sg) { sg.w[p >> 5] |= 1u << (p & 31); };
+        for (int k = 0; k < 8; ++k) if (F >> k & 1) set(g_in[k]);
+        if (a & 2) set(g_in[8]);
+        if (a & 1) set(g_in[9]);
+        if (F > 152) continue;
+        set(g_valid);
+        const int Fn = std::max(F + 1 - a, 1);
+        for (int k = 0; k < 8; ++k) if (Fn >> k & 1) set(g_target[k]);
+    }
 }
 
 static void setup(bool letter) {
@@ -113,11 +133,31 @@ static Net seed(bool letter) {
     return n;
 }
 
+static Net seed_deficit() {
+    Net n;
+    auto add = [&](int x, int y, int z, uint8_t t) { n.nodes.push_back(Node{{x, y, z}, t}); return 10 + (int)n.nodes.size() - 1; };
+    const int f[8] = {0, 1, 2, 3, 4, 5, 6, 7}, a1 = 8, a0 = 9;
+    const uint8_t OR3 = LUT(x | y | z), XOR3 = LUT(x ^ y ^ z), MAJ = LUT((x & y) | (x & z) | (y & z));
+    const int t1 = add(f[2], f[3], f[4], OR3), t2 = add(f[5], f[6], f[7], OR3);
+    const int g1 = add(t1, t2, f[1], OR3), g0 = add(t1, t2, f[0], OR3);
+    const int e1 = add(a1, g1, g1, LUT(x & y));
+    const int same = add(a1, g1, g1, LUT(~(x ^ y)));
+    const int pick = add(a1, g0, a0, LUT((x & y) | (~x & z)));
+    const int ag = add(a0, g0, g0, LUT(x & y));
+    const int e0 = add(same, ag, pick, LUT((x & y) | (~x & z)));
+    int c = add(f[0], e0, e0, LUT(x & ~y));
+    add(f[0], e0, e0, LUT(~(x ^ y)));
+    add(f[1], e1, c, XOR3); c = add(f[1], e1, c, MAJ);
+    for (int k = 2; k < 8; ++k) { add(f[k], e1, c, XOR3); if (k < 7) c = add(f[k], e1, c, MAJ); }
+    return n;
+}
+
 static void print_net(const Net& n, std::vector<Sig>& s, bool letter) {
     int outs[8];
     const int c = cost(n, s, outs);
     std::lock_guard<std::mutex> lk(g_mu);
-    printf("EXACT=%d %s cell, %d nodes; signals 0..3 = a3..a0, 4..7 = b3..b0%s; outputs a'3..a'0 b'3..b'0 = ", c == 0, letter ? "letter" : "N",
+    if (g_mode == 2) printf("EXACT=%d deficit step, %d nodes; signals 0..7 = f0..f7, 8 = a1, 9 = a0; outputs f'0..f'7 = ", c == 0, (int)n.nodes.size());
+    else printf("EXACT=%d %s cell, %d nodes; signals 0..3 = a3..a0, 4..7 = b3..b0%s; outputs a'3..a'0 b'3..b'0 = ", c == 0, letter ? "letter" : "N",
            (int)n.nodes.size(), letter ? ", 8 = neq" : "");
     for (int t = 0; t < 8; ++t) printf("s%d ", g_nin + outs[t]);
     printf("\n");
@@ -127,11 +167,25 @@ static void print_net(const Net& n, std::vector<Sig>& s, bool letter) {
 }
 
 int main(int argc, char** argv) {
-    const bool letter = argc < 2 || argv[1][0] != 'n';
+    const bool letter = argc < 2 || argv[1][0] == 'l';
+    g_mode = (argc > 1 && argv[1][0] == 'd') ? 2 : (letter ? 0 : 1);
     const int nthreads = argc > 2 ? atoi(argv[2]) : 4;
     const long iters = argc > 3 ? atol(argv[3]) : 400000;
-    setup(letter);
-    Net best = seed(letter);
+    if (g_mode == 2) setup_deficit(); else setup(letter);
+    Net best = g_mode == 2 ? seed_deficit() : seed(letter);
+    if (argc > 4) {                                      // continue from the last exact network of an earlier run's log
+        FILE* fh = fopen(argv[4], "r");
+        char line[512];
+        Net cur; bool exact = false;
+        while (fh && fgets(line, sizeof line, fh)) {
+            if (!strncmp(line, "EXACT=", 6)) { if (exact && !cur.nodes.empty()) best = cur; cur.nodes.clear(); exact = line[6] == '1'; continue; }
+            int sid, x, y, z; unsigned tab;
+            if (sscanf(line, " s%d = LUT[0x%x](s%d, s%d, s%d)", &sid, &tab, &x, &y, &z) == 5) cur.nodes.push_back(Node{{x, y, z}, (uint8_t)tab});
+        }
+        if (exact && !cur.nodes.empty()) best = cur;
+        if (fh) fclose(fh);
+    }
+    const unsigned long long seed0 = argc > 5 ? strtoull(argv[5], nullptr, 10) : 987654321ull;
     {
         std::vector<Sig> s(g_nin + best.nodes.size());
         if (cost(best, s) != 0) { fprintf(stderr, "the seed network is not exact\n"); print_net(best, s, letter); return 1; }
@@ -139,7 +193,7 @@ int main(int argc, char** argv) {
     }
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; ++t) th.emplace_back([=, &best] {
-        std::mt19937_64 rng(987654321ull + 7919ull * t);
+        std::mt19937_64 rng(seed0 + 7919ull * t);
         for (;;) {
             Net cur;
             { std::lock_guard<std::mutex> lk(g_mu); cur = best; }
