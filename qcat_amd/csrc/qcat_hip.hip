@@ -530,6 +530,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     // launches of a scan run concurrently
     PackedScratch* sc = &c->packed;
     sc->wspec = nullptr;                                  // interiors: no letter flags, no bit-sliced classes
+    sc->slim = false;                                     // ... and the barcode results stay in the interior's own records
     if ((rc = packed_prepare(st, hk, (uint32_t)slots, sc))) return set_err(rc, packed_last_error());
     const uint32_t tiles = (uint32_t)(slots / PK_TILE);
     fork_join(sc, st, hk.nt, [&](int t, hipStream_t q) {
@@ -540,7 +541,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     {
         const uint32_t fblocks = (uint32_t)std::min<uint64_t>((slots + 255) / 256, 2048);
         hipLaunchKernelGGL(k_adapter_finish, dim3(fblocks), dim3(256), 0, st, kp.kit, c->mid_len, (uint32_t)slots,
-                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1, (const uint8_t*)nullptr, sc->jobinfo);
+                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1, (const uint8_t*)nullptr, sc->jobinfo, (int2*)nullptr);
     }
     const int nsets = hk.mode == QCAT_MODE_DUAL ? 2 : 1;
     rc = packed_barcode(st, kp, hk, (uint32_t)slots, c->mid_recs, sc, [&](uint32_t max_tiles) {
@@ -626,6 +627,10 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     if (resume_kit_mask >= 0 && !(use_packed && c->packed.slices_single))
         return set_err(QCAT_ERR_UNSUPPORTED, "the adapter pass of this kit cannot be resumed per kit (table or general kernels)");
     c->packed.wspec = c->wspec; c->packed.win = c->win;
+    // packed barcode results (kernels_bitslice.inc: k_bs_select_ordered) instead of 8 bytes scattered into every record;
+    // debug scans keep the records complete for the traces
+    const bool slim = use_packed && !debug && hk.mode != QCAT_MODE_SIMPLE && getenv("QCAT_HIP_NO_SLIM") == nullptr;
+    c->packed.slim = slim;
     if (hk.mode == QCAT_MODE_SIMPLE) {
         uint32_t blocks = (uint32_t)((n_ends + GEN_THREADS - 1) / GEN_THREADS);
         hipLaunchKernelGGL(k_scan_simple, dim3(blocks), dim3(GEN_THREADS), 0, c->stream, kp, c->win, c->wlen, (uint32_t)n_ends, c->recs,
@@ -650,7 +655,8 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, hk.n_buckets > 2048 ? 512 : 4096);
         const bool middle = hk.scan_middle != 0;
         hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, c->stream,
-                           kp, c->recs, b->offsets, b->true_len, n, c->results, middle ? nullptr : c->counts);
+                           kp, c->recs, b->offsets, b->true_len, n, c->results, middle ? nullptr : c->counts,
+                           (slim && !adapter_only) ? c->packed.bcres : nullptr);
         mark(c, "k_finalize");
         if (middle) {
             const uint8_t* only = nullptr;
