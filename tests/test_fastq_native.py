@@ -1,0 +1,85 @@
+"""The native FASTQ record splitter (qcat_fastq_open, csrc/fastq_host.inc) on the CPU: it must index plain four-line ASCII
+FASTQ files exactly as the Python parser of the driver (which restates Biopython's FastqGeneralIterator) reads them, and
+answer "unsupported" -- so that the Python parser takes the file -- for everything that parser would read differently."""
+import os
+import random
+
+import pytest
+
+import helpers
+from qcat_amd import cli, native
+
+
+def _index(path):
+    fq = native.FastqFile(path)
+    try:
+        with open(path, "rb") as fh:
+            data = fh.read()
+        out = []
+        for r in range(fq.n_reads):
+            to, tl, so, sl = fq.read_info(r)
+            out.append((data[to:to + tl].decode(), data[so:so + sl].decode()))
+        return out
+    finally:
+        fq.close()
+
+
+def _python_records(path):
+    with open(path) as fh:
+        return [(t, s) for t, s, _q in cli._fastq_records(fh)]
+
+
+@pytest.mark.parametrize("name", ["nbd103.fastq", "pbk004.fastq", "rab204.fastq", "rbk004.fastq"])
+def test_shipped_files_index_like_the_python_parser(name):
+    path = os.path.join(helpers.GOLDEN, "data", name)
+    assert _index(path) == _python_records(path)
+
+
+def test_parallel_split_of_a_file_with_awkward_quality_lines(tmp_path, monkeypatch):
+    """Quality lines that begin with '@' or '+', titles with tabs and trailing blanks, a '+' line repeating the title, a last
+    record without a newline -- in a file big enough to be split over several threads (QCAT_HOST_THREADS)."""
+    rng = random.Random(7)
+    monkeypatch.setenv("QCAT_HOST_THREADS", "5")
+    lines = []
+    for i in range(60000):
+        n = rng.randrange(1, 400)
+        seq = "".join(rng.choice("ACGTN") for _ in range(n))
+        qual = "".join(rng.choice("@+!I5#") for _ in range(n))
+        title = "read%d" % i + rng.choice(["", " ch=1", "\tcomment with\ttabs", " trailing  "])
+        plus = "+" + (title.rstrip() if i % 7 == 0 else "")
+        lines += ["@" + title, seq, plus, qual]
+    path = str(tmp_path / "awkward.fastq")
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines))                       # (no newline after the last record)
+    assert os.path.getsize(path) > 5 * (4 << 20)         # more than one piece
+    got, want = _index(path), _python_records(path)
+    assert len(got) == 60000 and got == want
+
+
+@pytest.mark.parametrize("body", [
+    "@r1\nACGT\n+\nIIII\n\n@r2\nAC\n+\nII\n",           # blank line between records
+    "@r1\nAC\nGT\n+\nIIII\n",                           # wrapped sequence
+    "@r1\r\nACGT\r\n+\r\nIIII\r\n",                     # CRLF
+    "@r1\nACGT \n+\nIIII\n",                            # trailing blank on the sequence line
+    "@r1\nACGT\n+r2\nIIII\n",                           # '+' line with another title
+    "@r1\nACGT\n+\nIII\n",                              # quality shorter than the sequence
+    ">r1\nACGT\n",                                      # FASTA
+    "@r1\nAC\xc3\xa9T\n+\nIIII\n",                      # non-ASCII
+    "@r1\nACGT\n+\n",                                   # truncated
+])
+def test_anything_else_is_left_to_the_python_parser(body, tmp_path):
+    path = str(tmp_path / "odd.fastq")
+    with open(path, "w", encoding="latin-1") as fh:
+        fh.write(body)
+    with pytest.raises(native.FastqFile.Unsupported):
+        native.FastqFile(path)
+
+
+def test_empty_file_and_missing_file(tmp_path):
+    path = str(tmp_path / "empty.fastq")
+    open(path, "w").close()
+    fq = native.FastqFile(path)
+    assert fq.n_reads == 0
+    fq.close()
+    with pytest.raises(RuntimeError):
+        native.FastqFile(str(tmp_path / "nope.fastq"))
