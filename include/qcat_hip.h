@@ -376,7 +376,8 @@ typedef struct qcat_demux_opts {
 } qcat_demux_opts;
 typedef struct qcat_demux_stats {
     uint64_t n_reads, n_skipped, file_bytes;
-    double parse_s, scan_s, write_s;       /* record splitting; upload + kernels + download; formatting + write() */
+    double parse_s, scan_s, write_s;       /* record splitting (qcat_fastq_open); upload + kernels + download; formatting + write() */
+    double total_s;                        /* the call: the writers run beside the scan, so total_s < scan_s + write_s */
 } qcat_demux_stats;
 /* scans every read of the file with `kit` (QCAT_ENDS_BOTH) and writes the outputs; recs[r] / skipped[r] (n_reads entries
  * each, caller-owned) receive the record of read r and whether the minimum-length filter dropped it.

@@ -1023,6 +1023,7 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
     const uint64_t n = (uint64_t)hk.max_align;
     const bool both = hk.ends == QCAT_ENDS_BOTH;
     const uint64_t keep = both ? 2 * n : n;
+    const auto t_entry = std::chrono::steady_clock::now();
     if (!c->pipe) {
         c->pipe = new HostPipeline();
         c->pipe->pool = new HostPool(host_threads() - 1);
@@ -1045,7 +1046,10 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
     // (heavier per-chunk launches lose less to the tails of the persistent barcode kernels: large batches take 1 M-read chunks)
     // (a chunk costs ~0.3 ms of host time in launches and copies whatever its size: 1 M reads of a small kit run
     // 166 M reads/s in four chunks, 137 M in eight, 97 M in sixteen)
-    const uint32_t chunk = ce ? (uint32_t)std::max(4096, atoi(ce)) : std::min<uint32_t>(1048576u, std::max<uint32_t>(262144u, n_reads / 4u));
+    // (reads of a FASTQ mapping: a one-shot process pays for every pinned byte it sets up, 0.2 ms per MiB, and the host side
+    // bounds the rate anyway -- 256 k-read chunks)
+    const uint32_t chunk = ce ? (uint32_t)std::max(4096, atoi(ce))
+                              : (rv.recs ? 262144u : std::min<uint32_t>(1048576u, std::max<uint32_t>(262144u, n_reads / 4u)));
     // chunk boundaries: the first and the last chunk are a third of the others -- nothing overlaps the first chunk's
     // compaction and the last chunk's upload + scan + download
     std::vector<uint32_t> cuts;
@@ -1059,21 +1063,17 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
         cuts.push_back(n_reads);
     }
     const uint32_t n_chunks = (uint32_t)cuts.size() - 1;
-    if ((size_t)n_reads > p->cap_results) {
-        if (p->pin_results) (void)hipHostFree(p->pin_results);
-        p->pin_results = nullptr; p->cap_results = 0;
-        HIPCHK(hipHostMalloc((void**)&p->pin_results, (size_t)n_reads * sizeof(qcat_result)));
-        p->cap_results = n_reads;
-    }
     for (PipeStage& st : p->st) {
         const size_t need_reads = (size_t)chunk + 1, need_bases = (size_t)chunk * keep + 2 * BATCH_SLACK;
         if (need_reads > st.cap_reads) {
             if (st.pin_offsets) (void)hipHostFree(st.pin_offsets);
             if (st.pin_len) (void)hipHostFree(st.pin_len);
+            if (st.pin_results) (void)hipHostFree(st.pin_results);
             (void)hipFree(st.dev_offsets); (void)hipFree(st.dev_len);
-            st.pin_offsets = nullptr; st.pin_len = nullptr; st.dev_offsets = nullptr; st.dev_len = nullptr; st.cap_reads = 0;
+            st.pin_offsets = nullptr; st.pin_len = nullptr; st.pin_results = nullptr; st.dev_offsets = nullptr; st.dev_len = nullptr; st.cap_reads = 0;
             HIPCHK(hipHostMalloc((void**)&st.pin_offsets, need_reads * 8));
             HIPCHK(hipHostMalloc((void**)&st.pin_len, need_reads * 4));
+            HIPCHK(hipHostMalloc((void**)&st.pin_results, need_reads * sizeof(qcat_result)));
             HIPCHK(hipMalloc((void**)&st.dev_offsets, need_reads * 8));
             HIPCHK(hipMalloc((void**)&st.dev_len, need_reads * 4));
             st.cap_reads = need_reads;
@@ -1097,6 +1097,19 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
     double t_wait = 0, t_prefix = 0, t_compact = 0, t_enqueue = 0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
+    // a slot's records go to the caller's array once its scan is known to be done
+    auto flush_results = [&](PipeStage& st) {
+        if (!st.res_count) return;
+        const uint32_t cnt = st.res_count, first = st.res_first;
+        const int parts = (int)std::min<uint32_t>(p->pool->size(), std::max<uint32_t>(1u, cnt / 65536u));
+        const uint32_t per = (cnt + parts - 1) / parts;
+        p->pool->run(parts, [&](int part) {
+            const uint32_t a = std::min<uint32_t>(cnt, (uint32_t)part * per), b2 = std::min<uint32_t>(cnt, a + per);
+            if (b2 > a) memcpy(out + first + a, st.pin_results + a, (size_t)(b2 - a) * sizeof(qcat_result));
+        });
+        st.res_count = 0;
+    };
+    for (PipeStage& st : p->st) st.res_count = 0;
     for (uint32_t ci = 0; ci < n_chunks && !rc; ++ci) {
         PipeStage& st = p->st[ci & 1];
         double t0 = now();
@@ -1156,7 +1169,7 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
         t_compact += now() - t0; t0 = now();
         // this slot's device buffers are free again once the scan of chunk ci - 2 is done: waited for on the HOST, so
         // that the copy stream never holds a barrier packet behind which its copies would queue up
-        if (ci >= 2) HIPCHK(hipEventSynchronize(st.scanned));
+        if (ci >= 2) { HIPCHK(hipEventSynchronize(st.scanned)); flush_results(st); }
         if (total) HIPCHK(hipMemcpyAsync(st.dev_bases_alloc + BATCH_SLACK, st.pin_bases, total, hipMemcpyHostToDevice, p->copy));
         HIPCHK(hipMemcpyAsync(st.dev_offsets, st.pin_offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, p->copy));
         HIPCHK(hipMemcpyAsync(st.dev_len, st.pin_len, (size_t)nr * 4, hipMemcpyHostToDevice, p->copy));
@@ -1168,29 +1181,24 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
         view.offsets = st.dev_offsets; view.true_len = st.dev_len;
         rc = scan_resident_impl(c, kit, &view, false, 0, false, -1, /*keep_counts=*/ci > 0);
         if (rc) break;
-        HIPCHK(hipMemcpyAsync(p->pin_results + r0, c->results, (size_t)nr * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(st.pin_results, c->results, (size_t)nr * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipEventRecord(st.scanned, c->stream));
+        st.res_first = r0; st.res_count = nr;
         t_enqueue += now() - t0;
     }
     const double t_loop = now();
     hipError_t es = hipStreamSynchronize(c->stream);
     hipError_t ec = hipStreamSynchronize(p->copy);
     if (trace)
-        fprintf(stderr, "[qcat pipeline] %u reads, %u chunks, %u threads: staging wait %.2f ms, prefix %.2f, compaction %.2f, enqueue %.2f, "
-                        "drain %.2f, total so far %.2f ms\n", n_reads, n_chunks, p->pool->size(), t_wait, t_prefix, t_compact, t_enqueue,
+        fprintf(stderr, "[qcat pipeline] %u reads, %u chunks, %u threads: set-up (pool, pinned and device staging) %.2f ms, staging wait %.2f ms, "
+                        "prefix %.2f, compaction %.2f, enqueue %.2f, drain %.2f, total so far %.2f ms\n", n_reads, n_chunks, p->pool->size(),
+                t_begin - std::chrono::duration<double, std::milli>(t_entry.time_since_epoch()).count(), t_wait, t_prefix, t_compact, t_enqueue,
                 now() - t_loop, now() - t_begin);
     c->last_n_reads = 0;                                 // the context's result buffer holds the last chunk only
     if (rc) return rc;
     if (es != hipSuccess || ec != hipSuccess)
         return set_err(QCAT_ERR_DEVICE, std::string("qcat_scan_batch: ") + hipGetErrorString(es != hipSuccess ? es : ec));
-    {
-        const int parts = (int)std::min<uint32_t>(p->pool->size(), std::max<uint32_t>(1u, n_reads / 65536u));
-        const uint32_t per = (n_reads + parts - 1) / parts;
-        p->pool->run(parts, [&](int part) {
-            const uint32_t a = std::min<uint32_t>(n_reads, (uint32_t)part * per), b2 = std::min<uint32_t>(n_reads, a + per);
-            if (b2 > a) memcpy(out + a, p->pin_results + a, (size_t)(b2 - a) * sizeof(qcat_result));
-        });
-    }
+    for (PipeStage& st : p->st) flush_results(st);
     if (counts) {
         std::vector<int64_t> tmp((size_t)hk.n_buckets);
         c->last_buckets = hk.n_buckets;

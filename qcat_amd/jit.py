@@ -234,9 +234,11 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
             shape = _bs_shape(len(up), len(dn), m) if len(targets) <= 128 else None
             if shape:
                 rev, pre, own = shape
-                parts.append("struct QBSJ_%d {\n    static constexpr int C = %d, KERNEL = QCAT_JIT_BASE + %d;\n"
+                s1, s0 = _bs_shared_words(targets[0], rev, pre)
+                parts.append("struct QBSJ_%d {\n    static constexpr int C = %d, KERNEL = QCAT_JIT_BASE + %d, PRE = %d;\n"
+                             "    static constexpr unsigned S1 = 0x%Xu, S0 = 0x%Xu;\n"
                              "    static __device__ __forceinline__ void rows(int kase, const uint4* __restrict__ s_rows, int L, int lane, "
-                             "bool shared, u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n" % (g, own, g))
+                             "bool shared, u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n" % (g, own, g, pre, s1, s0))
                 for b, tg in enumerate(targets):
                     w1, w0 = _bs_words(tg, rev, pre)
                     parts.append("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(s_rows, L, lane, shared, h1, h0, f); break;\n" % (b, w1, w0))
@@ -268,6 +270,16 @@ def _bs_words(codes, rev, pre):
     t = codes[::-1] if rev else codes
     w1 = w0 = 0
     for j, c in enumerate(t[pre:]):
+        w1 |= ((c >> 1) & 1) << j
+        w0 |= (c & 1) << j
+    return w1, w0
+
+
+def _bs_shared_words(codes, rev, pre):
+    """letter bit words of the shared (leading context) columns: bit j = shared column j"""
+    t = codes[::-1] if rev else codes
+    w1 = w0 = 0
+    for j, c in enumerate(t[:pre]):
         w1 |= ((c >> 1) & 1) << j
         w0 |= (c & 1) << j
     return w1, w0

@@ -18,7 +18,7 @@ ENDS_5P, ENDS_BOTH = 1, 3
 MAX_TEMPLATES = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libqcat_hip.so")
+LIB_PATH = os.environ.get("QCAT_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libqcat_hip.so")   # (the override: A/B runs of two builds)
 
 
 class BarcodeSetDesc(C.Structure):
@@ -85,7 +85,7 @@ class DemuxOpts(C.Structure):
 
 class DemuxStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_skipped", C.c_uint64), ("file_bytes", C.c_uint64),
-                ("parse_s", C.c_double), ("scan_s", C.c_double), ("write_s", C.c_double)]
+                ("parse_s", C.c_double), ("scan_s", C.c_double), ("write_s", C.c_double), ("total_s", C.c_double)]
 
 
 class KitDescriptor(object):
@@ -597,7 +597,7 @@ class FastqFile(object):
             raise FastqFile.Unsupported((self.hip.lib.qcat_last_error() or b"").decode("utf-8", "replace"))
         self.hip.check(rc)
         return recs, skipped, {"n_reads": int(st.n_reads), "n_skipped": int(st.n_skipped), "file_bytes": int(st.file_bytes),
-                               "parse_s": st.parse_s, "scan_s": st.scan_s, "write_s": st.write_s}
+                               "parse_s": st.parse_s, "scan_s": st.scan_s, "write_s": st.write_s, "total_s": st.total_s}
 
     def close(self):
         if self.handle:

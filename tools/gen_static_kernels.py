@@ -79,6 +79,17 @@ def bs_words(target, rev, pre, code):
     return w1, w0
 
 
+def bs_shared_words(target, rev, pre, code):
+    """letter bit words of the shared (leading context) columns: bit j = shared column j"""
+    t = target[::-1] if rev else target
+    w1 = w0 = 0
+    for j, ch in enumerate(t[:pre]):
+        c = code[ch]
+        w1 |= ((c >> 1) & 1) << j
+        w0 |= (c & 1) << j
+    return w1, w0
+
+
 def pair_up(targets, flank):
     """greedy pairing by longest common prefix: [(ta, tb, shared columns)]; a leftover target is paired
     with itself.  Two targets that run in one row pass share their common prefix columns, so the
@@ -227,7 +238,9 @@ def render():
                 bh = _Buf()
                 bh.write("struct QBS_%d {      // %s + barcode + %s: %s, %d shared + %d own columns, %d targets\n"
                          % (kid, up, dn, "reversed" if rev else "forward", pre, own, len(targets)))
-                bh.write("    static constexpr int C = %d, KERNEL = %d;\n" % (own, kid))
+                s1, s0 = bs_shared_words(targets[0], rev, pre, CODE)
+                bh.write("    static constexpr int C = %d, KERNEL = %d, PRE = %d;\n    static constexpr unsigned S1 = 0x%Xu, S0 = 0x%Xu;      // letters of the shared columns\n"
+                         % (own, kid, pre, s1, s0))
                 bh.write("    static __device__ __forceinline__ void rows(int kase, const uint4* __restrict__ s_rows, int L, int lane, bool shared, "
                          "u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n")
                 for pr, (ta, tb, up_) in enumerate(pairs):
