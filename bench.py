@@ -268,7 +268,7 @@ def main():
         # first 2 M reads: N ranks x 9.5 GB of pageable host copies are not needed to see the rate), then time
         # qcat_scan_batch (upload + scan + 24 B/read download) three times, keep the fastest; at N > 1 all
         # ranks run it at the same time under the launcher's CPU split and the slowest rank counts
-        hi = host_inclusive(a, hip, lib, ctx, kit, cfg, ends, batch, sp, nb.value, recs, comm, world)
+        hi = host_inclusive(a, hip, lib, ctx, kit, cfg, ends, batch, sp, nb.value, recs, comm, world, det, mode)
         if rank == 0:
             out["host_inclusive"] = hi
     if rank == 0:
@@ -283,7 +283,50 @@ def main():
         comm.close()
 
 
-def host_inclusive(a, hip, lib, ctx, kit, cfg, ends, batch, sp, n_bases, recs, comm, world):
+def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
+    """The same reads from a FASTQ FILE: qcat_fastq_open (mmap + record splitting on the host threads) and
+    qcat_fastq_demux (scan straight from the mapping, TSV written beside the scan) on the first min(n, 1 M) reads,
+    records compared with the resident scan's.  File-to-TSV rate of the native driver path (host-bound)."""
+    import tempfile
+    m = min(n, 1000000)
+    tmp = tempfile.mkdtemp(prefix="qcat_bench_fq_")
+    path = os.path.join(tmp, "reads.fastq")
+    raw = hb[:int(ho[m])].tobytes()
+    qual = b"I" * 65536
+    with open(path, "wb") as fh:
+        for i in range(m):
+            s = raw[int(ho[i]):int(ho[i + 1])]
+            fh.write(b"@r%d ch=%d\n%s\n+\n%s\n" % (i, 1 + i % 512, s, qual[:len(s)] if len(s) <= 65536 else b"I" * len(s)))
+    size = os.path.getsize(path)
+    native.FastqFile(path).close()                   # (page cache warm, as after the file was just written)
+    best = None
+    with open(os.path.join(tmp, "calls.tsv"), "wb") as sink:
+        for _ in range(2):                           # (the first call sizes the context's staging buffers)
+            sink.seek(0)
+            t1 = time.perf_counter()
+            fq = native.FastqFile(path)
+            got, _skipped, st = fq.demux(ctx, kit, det.layouts, mode == "dual", kit_auto=False, trim=True, min_read_length=0,
+                                         tsv_fd=sink.fileno())
+            dt = time.perf_counter() - t1
+            fq.close()
+            if best is None or dt < best[0]:
+                best = (dt, st)
+    same = got.tobytes() == recs[:m].tobytes()
+    for f in os.listdir(tmp):
+        os.remove(os.path.join(tmp, f))
+    os.rmdir(tmp)
+    if not same:
+        sys.exit("bench.py: the scan of the FASTQ file and the resident scan disagree")
+    dt, st = best
+    return {"value": round(m / dt, 1), "unit": "reads/s", "reads": m, "file_gb": round(size / 1e9, 3),
+            "parse_gb_per_s": round(size / st["parse_s"] / 1e9, 2),
+            "split_s": {k: round(st[k], 4) for k in ("parse_s", "scan_s", "write_s", "total_s")},
+            "note": "qcat_fastq_open + qcat_fastq_demux of a FASTQ file of the first reads, TSV out (one line per read); "
+                    "records identical to the resident scan's; host-bound: parse_s = record splitting of the whole file, "
+                    "the writers run beside the scan (total_s = the demux call)"}
+
+
+def host_inclusive(a, hip, lib, ctx, kit, cfg, ends, batch, sp, n_bases, recs, comm, world, det, mode):
     n = a.reads if world == 1 else min(a.reads, 2000000)
     small = None
     if n < a.reads:
@@ -319,7 +362,9 @@ def host_inclusive(a, hip, lib, ctx, kit, cfg, ends, batch, sp, n_bases, recs, c
         sys.exit("bench.py: the host-buffer scan and the resident scan disagree")
     keep = cfg.max_align_length * (1 if ends == native.ENDS_5P else 2)
     up = int(ho[n]) if a.workload == "middle" else int(np.minimum(np.diff(ho).astype(np.int64), keep).sum())
-    return {"value": round(world * n / best, 1), "unit": "reads/s", "reads_per_gpu": n, "host_threads_per_rank":
+    # (the native FASTQ driver scans both ends, like qcat's own driver: workloads on a both-ends kit, one process)
+    fq_leg = from_fastq(ctx, kit, det, mode, hb, ho, n, recs) if (world == 1 and ends == native.ENDS_BOTH and a.workload != "middle") else None
+    return {"from_fastq": fq_leg, "value": round(world * n / best, 1), "unit": "reads/s", "reads_per_gpu": n, "host_threads_per_rank":
             int(os.environ.get("QCAT_HOST_THREADS", "0")) or min(usable_cores(), 16),
             "note": "qcat_scan_batch from pageable host memory (%.0f MB of reads per rank), records identical to the "
                     "resident scan's: chunks of 256 k to 1 M reads are compacted to their scanned windows on host "
