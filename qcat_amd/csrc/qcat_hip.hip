@@ -541,7 +541,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     {
         const uint32_t fblocks = (uint32_t)std::min<uint64_t>((slots + 255) / 256, 2048);
         hipLaunchKernelGGL(k_adapter_finish, dim3(fblocks), dim3(256), 0, st, kp.kit, c->mid_len, (uint32_t)slots,
-                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1, (const uint8_t*)nullptr, sc->jobinfo, (int2*)nullptr);
+                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1, (const uint8_t*)nullptr, sc->jobinfo, (int2*)nullptr, (uint32_t*)nullptr);
     }
     const int nsets = hk.mode == QCAT_MODE_DUAL ? 2 : 1;
     rc = packed_barcode(st, kp, hk, (uint32_t)slots, c->mid_recs, sc, [&](uint32_t max_tiles) {
@@ -656,7 +656,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         const bool middle = hk.scan_middle != 0;
         hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, c->stream,
                            kp, c->recs, b->offsets, b->true_len, n, c->results, middle ? nullptr : c->counts,
-                           (slim && !adapter_only) ? c->packed.bcres : nullptr);
+                           (slim && !adapter_only) ? c->packed.bcres : nullptr, (slim && !adapter_only) ? c->packed.fin : nullptr);
         mark(c, "k_finalize");
         if (middle) {
             const uint8_t* only = nullptr;
