@@ -654,7 +654,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         // when the bucket vector is long (dual kits)
         uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, hk.n_buckets > 2048 ? 512 : 4096);
         const bool middle = hk.scan_middle != 0;
-        hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), fin_lds_bytes(hk.n_buckets, !middle), c->stream,
                            kp, c->recs, b->offsets, b->true_len, n, c->results, middle ? nullptr : c->counts,
                            (slim && !adapter_only) ? c->packed.bcres : nullptr, (slim && !adapter_only) ? c->packed.fin : nullptr);
         mark(c, "k_finalize");
