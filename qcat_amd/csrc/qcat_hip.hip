@@ -544,7 +544,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
                            c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1, (const uint8_t*)nullptr, sc->jobinfo, (int2*)nullptr, (uint32_t*)nullptr);
     }
     const int nsets = hk.mode == QCAT_MODE_DUAL ? 2 : 1;
-    rc = packed_barcode(st, kp, hk, (uint32_t)slots, c->mid_recs, sc, [&](uint32_t max_tiles) {
+    rc = packed_barcode(st, kp, hk, (uint32_t)slots, c->mid_recs, sc, [&](uint32_t max_tiles, const BsPlan*) {
         const uint64_t gthreads = (uint64_t)max_tiles * 64 * (WIN_STRIDE / 16);
         hipLaunchKernelGGL(k_mid_gather, dim3((uint32_t)((gthreads + 255) / 256)), dim3(256), 0, st,
                            b->bases, b->offsets, hk.max_align, c->mid_sorted, c->mid_recs, sc->sorted, sc->jt, nsets,
@@ -572,7 +572,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     const size_t n_ends = (size_t)n * ends;
     if (n_ends >= (1ull << 31)) return set_err(QCAT_ERR_UNSUPPORTED, "batch too large (>= 2^31 read ends)");
 
-    if ((rc = grow(&c->win, &c->cap_win, n_ends * WIN_STRIDE + 64))) return rc;     // + slack: k_job_gather reads whole dwords
+    if ((rc = grow(&c->win, &c->cap_win, n_ends * WIN_STRIDE + 512))) return rc;    // + slack: k_job_gather reads whole dwords, k_bs_barcode 84 bytes from any region start
     if ((rc = grow(&c->wlen, &c->cap_wlen, n_ends))) return rc;
     if ((rc = grow(&c->wspec, &c->cap_wspec, n_ends))) return rc;
     if ((rc = grow(&c->recs, &c->cap_recs, n_ends))) return rc;
