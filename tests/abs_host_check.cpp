@@ -123,6 +123,77 @@ static int check_plan(const char* name, const std::string* tpls, int rounds, int
     return bad;
 }
 
+// a plan of four stages (QAM_*): the stages of a row one after the other, each handing its differences to the next
+template <class P>
+static int check_multi(const char* name, const std::string* tpls, int rounds, int L) {
+    static_assert(P::NS == 4, "four stages");
+    typedef typename P::S0 A0; typedef typename P::S1 A1; typedef typename P::S2 A2; typedef typename P::S3 A3;
+    int8_t mat[49];
+    adapter_matrix(mat);
+    int bad = 0;
+    for (int r = 0; r < rounds; ++r) {
+        std::vector<std::string> win(32);
+        for (auto& w : win) w = make_window(tpls, P::NT, L);
+        std::vector<u32> c1((size_t)L), c0((size_t)L);
+        for (int i = 0; i < L; ++i)
+            for (int b = 0; b < 32; ++b) {
+                const int code = (int)(strchr(BASES, win[(size_t)b][(size_t)i]) - BASES);
+                c1[(size_t)i] |= (u32)((code >> 1) & 1) << b;
+                c0[(size_t)i] |= (u32)(code & 1) << b;
+            }
+        static u32 h0[A0::NC][4], h1[A1::NC][4], h2[A2::NC][4], h3[A3::NC][4];
+        for (int j = 0; j < A0::NC; ++j) abs_set2(h0[j]);
+        for (int j = 0; j < A1::NC; ++j) abs_set2(h1[j]);
+        for (int j = 0; j < A2::NC; ++j) abs_set2(h2[j]);
+        for (int j = 0; j < A3::NC; ++j) abs_set2(h3[j]);
+        AbsBorder b0[A0::BD], b1[A1::BD], b2[A2::BD], b3[A3::BD];
+        memset(b0, 0, sizeof b0); memset(b1, 0, sizeof b1); memset(b2, 0, sizeof b2); memset(b3, 0, sizeof b3);
+        for (int i = 0; i < L; ++i) {
+            u32 nq[4], x0[A0::HI][4], o0[A0::HO][4], o1[A1::HO][4], o2[A2::HO][4], o3[A3::HO][4];
+            const u32 first = i == 0 ? 0xFFFFFFFFu : 0u;
+            abs_neq_masks(c1[(size_t)i], c0[(size_t)i], nq);
+            A0::row(nq, h0, x0, o0, b0, first, (unsigned)i);
+            A1::row(nq, h1, o0, o1, b1, first, (unsigned)i);
+            A2::row(nq, h2, o1, o2, b2, first, (unsigned)i);
+            A3::row(nq, h3, o2, o3, b3, first, (unsigned)i);
+        }
+        AbsLastRow y0[A0::HI], l0[A0::HO], l1[A1::HO], l2[A2::HO], l3[A3::HO], r0[A0::BD], r1[A1::BD], r2[A2::BD], r3[A3::BD];
+        A0::last(h0, y0, l0, r0);
+        A1::last(h1, l0, l1, r1);
+        A2::last(h2, l1, l2, r2);
+        A3::last(h3, l2, l3, r3);
+        AbsBorder bd[2]; AbsLastRow lr[2];
+        int seen = 0;
+        auto take = [&](int t, const AbsBorder& b, const AbsLastRow& l) { if (t >= 0) { bd[t] = b; lr[t] = l; ++seen; } };
+        take(A0::BT0, b0[0], r0[0]); if (A0::NBD > 1) take(A0::BT1, b0[A0::BD - 1], r0[A0::BD - 1]);
+        take(A1::BT0, b1[0], r1[0]); if (A1::NBD > 1) take(A1::BT1, b1[A1::BD - 1], r1[A1::BD - 1]);
+        take(A2::BT0, b2[0], r2[0]); if (A2::NBD > 1) take(A2::BT1, b2[A2::BD - 1], r2[A2::BD - 1]);
+        take(A3::BT0, b3[0], r3[0]); if (A3::NBD > 1) take(A3::BT1, b3[A3::BD - 1], r3[A3::BD - 1]);
+        if (seen != P::NT) { fprintf(stderr, "%s: %d borders for %d templates\n", name, seen, P::NT); return 1000; }
+        for (int t = 0; t < P::NT; ++t) {
+            u32 val[ABS_NF + 1], endq[ABS_NI];
+            abs_decide(bd[t], lr[t], (unsigned)(L - 1), val, endq);
+            const int M = (int)tpls[t].size();
+            for (int b = 0; b < 32; ++b) {
+                int v = 0, e = 0;
+                for (int k = 0; k <= ABS_NF; ++k) v |= (int)((val[k] >> b) & 1u) << k;
+                for (int k = 0; k < ABS_NI; ++k) e |= (int)((endq[k] >> b) & 1u) << k;
+                const int score = v - 2 * M - 1;
+                int32_t ws, wq, wr;
+                qo_sg(win[(size_t)b].c_str(), L, tpls[t].c_str(), M, 2, 2, mat, &ws, &wq, &wr);
+                if (score != ws || e != wq) {
+                    if (bad < 10)
+                        fprintf(stderr, "%s round %d template %d alignment %d: got (%d, %d), oracle (%d, %d)\n  %s\n", name, r, t, b,
+                                score, e, ws, wq, win[(size_t)b].c_str());
+                    ++bad;
+                }
+            }
+        }
+    }
+    printf("%s: %d rounds x 32 alignments x %d template(s), L = %d: %d mismatches\n", name, rounds, P::NT, L, bad);
+    return bad;
+}
+
 // the searched cell networks against the reference forms, on every valid input (a, b in 0..9, both letter outcomes)
 static int check_cells() {
     int bad = 0;

@@ -587,9 +587,12 @@ def test_bit_sliced_adapter_kernels_equal_the_binary16_kernels_and_the_oracle(mo
     bases, offsets = native.pack_reads(reads)
     lib = native.HipLibrary.get().lib
     has_plan = True                                             # (dual kit: its 83-column template has one, the 98-column one not)
-    for variant in ("forced", "off"):
-        if variant == "forced":
+    # forced with the two-stage plans everywhere, forced with the four-stage plans where a template has one (the
+    # medium-batch form, k_adapter_ms), switched off
+    for variant in ("forced", "forced4", "off"):
+        if variant.startswith("forced"):
             monkeypatch.setenv("QCAT_HIP_ADAPTER_BITSLICE_MIN", "1")
+            monkeypatch.setenv("QCAT_HIP_ABS_STAGES", "4" if variant == "forced4" else "2")
         else:
             monkeypatch.setenv("QCAT_HIP_NO_ADAPTER_BITSLICE", "1")
         cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
@@ -599,7 +602,7 @@ def test_bit_sliced_adapter_kernels_equal_the_binary16_kernels_and_the_oracle(mo
         names = (C.c_char_p * 16)()
         ms = (C.c_float * 16)()
         ran = [names[i].decode() for i in range(lib.qcat_ctx_last_timing(ctx.handle, names, ms, 16))]
-        assert ("k_adapter_bitslice" in ran) == (variant == "forced" and has_plan), (variant, ran)
+        assert ("k_adapter_bitslice" in ran) == (variant.startswith("forced") and has_plan), (variant, ran)
         for name in native.TRACE_DTYPE.names:
             bad = np.nonzero(np.asarray(traces[name] != o_traces[name]).reshape(len(traces), -1).any(axis=1))[0]
             assert len(bad) == 0, (variant, name, bad[:10], traces[name][bad[:3]], o_traces[name][bad[:3]])

@@ -172,6 +172,146 @@ def emit_plan(name, seqs, comment):
     return "".join(out)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# plans of MS_STAGES stages (k_adapter_ms, kernels_abs.inc): the same linear program cut into four pieces, one wave each.
+# A stage may hold borders (it then owns that template's end-position state and writes its result); every cut hands over
+# the running difference and, between fork and resume, the forked one.  Four waves per tile: twice the waves of the
+# two-stage plans for the same tiles -- for MEDIUM batches (1.5 to 3.5 tiles per CU), where a two-wave workgroup per tile
+# leaves the SIMDs with one wave each.  Emitted for single templates whose stages hold at most MS_MAX_COLUMNS columns: those
+# compile to 128 VGPRs (four waves per SIMD, two templates' kernels side by side fit the chip).  Wider stages (168 VGPRs)
+# and the fused two-template plans were measured and lose (profiles/r03_ab_adapter_stages.txt).
+# ---------------------------------------------------------------------------------------------------------------------
+MS_STAGES = 4
+MS_MAX_COLUMNS = 13                                  # 4 planes per column + ~70 working registers <= 128 VGPRs
+
+
+def fork_live_at(ops, p):
+    return any(o[0] == "fork" for o in ops[:p]) and any(o[0] == "resume" for o in ops[p:])
+
+
+def multi_cuts(ops, ns, maxc):
+    """cut positions (ns - 1 of them, ops[:c0] = stage 0, ...) minimising the largest stage cost; None if a stage cannot
+    keep its columns in registers"""
+    import itertools
+    cand = [i + 1 for i, o in enumerate(ops[:-1]) if o[0] == "col" and ops[i + 1][0] != "border"]
+    pre = [0]
+    for o in ops:
+        pre.append(pre[-1] + op_cost(o))
+    colpre = [0]
+    for o in ops:
+        colpre.append(colpre[-1] + (1 if o[0] == "col" else 0))
+    live = {c: (2 if fork_live_at(ops, c) else 1) for c in cand}
+    best, best_cuts = None, None
+    for cuts in itertools.combinations(cand, ns - 1):
+        b = (0,) + cuts + (len(ops),)
+        worst = 0
+        ok = True
+        for k in range(ns):
+            lo, hi = b[k], b[k + 1]
+            nc = colpre[hi] - colpre[lo]
+            if nc < 1 or nc > maxc:
+                ok = False
+                break
+            c = pre[hi] - pre[lo] + COST["stage1"]
+            if k > 0:
+                c += COST["handover"] * live[lo]
+            if k < ns - 1:
+                c += COST["handover"] * live[hi]
+            worst = max(worst, c)
+        if ok and (best is None or worst < best):
+            best, best_cuts = worst, cuts
+    return best_cuts
+
+
+def emit_multi(name, seqs, comment, ns=MS_STAGES, maxc=MS_MAX_COLUMNS):
+    ops = program(seqs)
+    cuts = multi_cuts(ops, ns, maxc)
+    if cuts is None:
+        return None
+    b = (0,) + tuple(cuts) + (len(ops),)
+    nt = len(seqs)
+    out = ["// %s, %d stages\n" % (comment, ns)]
+    for i, q in enumerate(seqs):
+        out.append("//   template %d (%d columns): %s\n" % (i, len(q), q))
+    out.append("struct %s {\n" % name)
+    out.append("    static constexpr int NS = %d, NT = %d;\n" % (ns, nt))
+    out.append("    static constexpr int M0 = %d, M1 = %d;\n" % (len(seqs[0]), len(seqs[1]) if nt > 1 else 0))
+    ring_off, off = [], 0
+    for k in range(ns - 1):
+        nho = 2 if fork_live_at(ops, b[k + 1]) else 1
+        ring_off.append(off)
+        off += 2 * 4 * nho                               # planes of the cut's two ring buffers per row (x ABS_R x 64 words)
+    out.append("    static constexpr int RING_PLANES = %d;      // hand-over planes of all cuts, both buffers, per ring row\n" % off)
+
+    def cell(j, c):
+        if c == "N":
+            return "abs_cell_n(a, h[%d]);" % j
+        return "abs_cell_letter(nq[%d], a, h[%d]);" % (LETTER[c], j)
+
+    for k in range(ns):
+        sops = ops[b[k]:b[k + 1]]
+        nhi = 0 if k == 0 else (2 if fork_live_at(ops, b[k]) else 1)
+        nho = 0 if k == ns - 1 else (2 if fork_live_at(ops, b[k + 1]) else 1)
+        nc = sum(1 for o in sops if o[0] == "col")
+        borders = [o[1] for o in sops if o[0] == "border"]
+        need_f = nhi == 2 or any(o[0] == "fork" for o in sops)
+        out.append("    struct S%d {      // %d columns, cost model %d instructions per row\n"
+                   % (k, nc, sum(op_cost(o) for o in sops)))
+        out.append("        static constexpr int NC = %d, NHI = %d, NHO = %d, NBD = %d, HI = %d, HO = %d, BD = %d, BT0 = %d, BT1 = %d, RING_IN = %d, RING_OUT = %d;\n"
+                   % (nc, nhi, nho, len(borders), max(1, nhi), max(1, nho), max(1, len(borders)),
+                      borders[0] if borders else -1, borders[1] if len(borders) > 1 else -1,
+                      ring_off[k - 1] if k > 0 else -1, ring_off[k] if k < ns - 1 else -1))
+        # ---- one DP row ----
+        body, j = [], 0
+        if nhi:
+            body.append("ABS_COPY4(a, hi[%d]);" % (nhi - 1))
+            if nhi == 2:
+                body.append("ABS_COPY4(f, hi[0]);")
+        for o in sops:
+            if o[0] == "start":
+                body.append("abs_set2(a);")
+            elif o[0] == "col":
+                body.append(cell(j, o[1])); j += 1
+            elif o[0] == "fork":
+                body.append("ABS_COPY4(f, a);")
+            elif o[0] == "resume":
+                body.append("ABS_COPY4(a, f);")
+            elif o[0] == "border":
+                bi = borders.index(o[1])
+                body.append("{ const u32 nm = abs_border_step(bd[%d].Fc, a, first); abs_latch_index(bd[%d].ic, nm, row); }" % (bi, bi))
+        if nho:
+            if nho == 2:
+                body.append("ABS_COPY4(ho[0], f);")
+            body.append("ABS_COPY4(ho[%d], a);" % (nho - 1))
+        out.append("        static ABS_FN void row(const u32 (&nq)[4], u32 (&h)[NC][4], const u32 (&hi)[HI][4], u32 (&ho)[HO][4], AbsBorder (&bd)[BD], u32 first, unsigned row) {\n"
+                   "            u32 a[4]%s;\n            %s\n        }\n" % (", f[4]" if need_f else "", "\n            ".join(body)))
+        # ---- the walk along the last row ----
+        body, j, first = [], 0, False
+        if nhi:
+            body.append("r = li[%d];" % (nhi - 1))
+            if nhi == 2:
+                body.append("rf = li[0];")
+        for o in sops:
+            if o[0] == "start":
+                body.append("abs_lastrow_init(r);"); first = True
+            elif o[0] == "col":
+                body.append("abs_lastrow_step(r, h[%d], %s);" % (j, "true" if first else "false")); j += 1; first = False
+            elif o[0] == "fork":
+                body.append("rf = r;")
+            elif o[0] == "resume":
+                body.append("r = rf;")
+            elif o[0] == "border":
+                body.append("lr[%d] = r;" % borders.index(o[1]))
+        if nho:
+            if nho == 2:
+                body.append("lo[0] = rf;")
+            body.append("lo[%d] = r;" % (nho - 1))
+        out.append("        static ABS_FN void last(const u32 (&h)[NC][4], const AbsLastRow (&li)[HI], AbsLastRow (&lo)[HO], AbsLastRow (&lr)[BD]) {\n"
+                   "            AbsLastRow r%s;\n            %s\n        }\n    };\n" % (", rf" if need_f else "", "\n            ".join(body)))
+    out.append("};\n\n")
+    return "".join(out)
+
+
 def render():
     _fams, templates, fused, _members = gsk.collect()
     out = ["// generated by tools/gen_abs_kernels.py -- do not edit.  Column programs of the bit-sliced adapter kernels\n"
@@ -179,12 +319,15 @@ def render():
            "// (g_static_fused[n]), QAB_T<n> = adapter template n (g_static_templates, kernel n).\n"
            "#define ABS_COPY4(D, S) do { (D)[0] = (S)[0]; (D)[1] = (S)[1]; (D)[2] = (S)[2]; (D)[3] = (S)[3]; } while (0)\n"
            "namespace qabs {\n\n"]
-    have_f, have_t = [], []
+    have_f, have_t, have_mt = [], [], []
     cases = ["// generated by tools/gen_abs_kernels.py -- do not edit.  The plans of abs_generated.inc with their template\n"
              "// sequences, for tests/abs_host_check.cpp (rows: a full window, and an odd length).\n"]
 
     def case(name, seqs):
         cases.append("{ const std::string t[%d] = {%s};\n  bad += check_plan<%s>(\"%s\", t, rounds, 150); bad += check_plan<%s>(\"%s\", t, rounds / 4 + 1, 97); }\n"
+                     % (len(seqs), ", ".join('"%s"' % q for q in seqs), name, name, name, name))
+    def mcase(name, seqs):
+        cases.append("{ const std::string t[%d] = {%s};\n  bad += check_multi<%s>(\"%s\", t, rounds, 150); bad += check_multi<%s>(\"%s\", t, rounds / 4 + 1, 97); }\n"
                      % (len(seqs), ", ".join('"%s"' % q for q in seqs), name, name, name, name))
     for fid, (sa, sb) in enumerate(fused):
         u = len(os.path.commonprefix([sa, sb]))
@@ -195,11 +338,16 @@ def render():
         text = emit_plan("QAB_T%d" % tid, [seq], "adapter template %d" % tid)
         if text:
             out.append(text); have_t.append(tid); case("QAB_T%d" % tid, [seq])
+        text = emit_multi("QAM_T%d" % tid, [seq], "adapter template %d" % tid)
+        if text:
+            out.append(text); have_mt.append(tid); mcase("QAM_T%d" % tid, [seq])
     render.cases = "".join(cases)
     out.append("}  // namespace qabs\n#undef ABS_COPY4\n\n")
     out.append("// X(id): the plans that exist (templates whose stage would not fit a wave's registers have none)\n")
     out.append("#define QCAT_ABS_FOR_EACH_FUSED(X) %s\n" % " ".join("X(%d)" % i for i in have_f))
     out.append("#define QCAT_ABS_FOR_EACH_TEMPLATE(X) %s\n" % " ".join("X(%d)" % i for i in have_t))
+    out.append("// ... and the single-template plans of %d stages (QAM_T<n>)\n" % MS_STAGES)
+    out.append("#define QCAT_ABS_FOR_EACH_TEMPLATE_MS(X) %s\n" % " ".join("X(%d)" % i for i in have_mt))
     return "".join(out), len(have_f), len(have_t)
 
 
