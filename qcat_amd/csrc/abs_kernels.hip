@@ -8,13 +8,13 @@
 #include "kernels_abs.inc"
 
 // planes + eligibility of `n_tiles` tiles (k_abs_planes)
-extern "C" void qcat_abs_launch_planes(unsigned n_tiles, void* stream, const uint8_t* win, const int32_t* wlen, const uint8_t* wspec,
+extern "C" void qcat_abs_launch_planes(unsigned n_tiles, void* stream, const uint32_t* win2, const int32_t* wlen, const uint8_t* wspec,
                                        uint32_t n_ends, int rows, void* planes, uint32_t* valid, uint8_t* need128, uint32_t* tile_any) {
     if (rows == 150)
-        hipLaunchKernelGGL(qk::k_abs_planes<150>, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), win, wlen, wspec, n_ends, rows,
+        hipLaunchKernelGGL(qk::k_abs_planes<150>, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), win2, wlen, wspec, n_ends, rows,
                            static_cast<uint2*>(planes), valid, need128, tile_any);
     else
-        hipLaunchKernelGGL(qk::k_abs_planes<0>, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), win, wlen, wspec, n_ends, rows,
+        hipLaunchKernelGGL(qk::k_abs_planes<0>, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), win2, wlen, wspec, n_ends, rows,
                            static_cast<uint2*>(planes), valid, need128, tile_any);
 }
 

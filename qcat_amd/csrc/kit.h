@@ -25,6 +25,7 @@ constexpr int MAX_TLEN = QCAT_MAX_TEMPLATE_LEN;
 constexpr int MAX_TARGET = QCAT_MAX_TARGET_LEN;
 constexpr int MAX_WIN = QCAT_MAX_WINDOW;
 constexpr int WIN_STRIDE = 160;          // bytes per packed code window (16-B aligned rows)
+constexpr int WIN2_WORDS = WIN_STRIDE / 16; // dwords of a window at two bits per code (k_pack_windows: win2)
 constexpr int RAW_NEVER = 1 << 20;       // "no raw score passes"
 constexpr int PADMAX = 8;                // most leading padding columns a width class may have
 

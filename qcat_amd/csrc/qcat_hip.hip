@@ -380,6 +380,8 @@ struct qcat_ctx {
     uint8_t* win = nullptr;
     int32_t* wlen = nullptr;
     uint8_t* wspec = nullptr; size_t cap_wspec = 0;     // per read end: the window holds a letter outside A, C, G, T, N
+    uint32_t* win2 = nullptr; size_t cap_win2 = 0;      // the windows at two bits per code (plain windows: the bit-sliced kernels' input)
+    bool win2_valid = false;                            // ... written by the pack kernel of the windows in `win`
     EndRec* recs = nullptr;
     qcat_result* results = nullptr;
     unsigned long long* counts = nullptr;
@@ -439,7 +441,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->wspec); (void)hipFree(c->recs); (void)hipFree(c->results);
+    (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->wspec); (void)hipFree(c->win2); (void)hipFree(c->recs); (void)hipFree(c->results);
     (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows);
     (void)hipFree(c->hb_bases); (void)hipFree(c->hb_offsets); (void)hipFree(c->hb_len); (void)hipFree(c->vote_buf);
     packed_scratch_free(&c->packed);
@@ -575,6 +577,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     if ((rc = grow(&c->win, &c->cap_win, n_ends * WIN_STRIDE + 512))) return rc;    // + slack: k_job_gather reads whole dwords, k_bs_barcode 84 bytes from any region start
     if ((rc = grow(&c->wlen, &c->cap_wlen, n_ends))) return rc;
     if ((rc = grow(&c->wspec, &c->cap_wspec, n_ends))) return rc;
+    if ((rc = grow(&c->win2, &c->cap_win2, n_ends * WIN2_WORDS + 64))) return rc;      // + slack: readers take whole dwords past a region's end
     if ((rc = grow(&c->recs, &c->cap_recs, n_ends))) return rc;
     if ((rc = grow(&c->results, &c->cap_reads, (size_t)n))) return rc;
     if ((rc = grow(&c->counts, &c->cap_buckets, (size_t)hk.n_buckets))) return rc;
@@ -617,16 +620,18 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
             qcat_abs_launch_pack_planes(tiles, c->stream, b->bases, b->offsets, n, ends, c->win, c->wlen, c->wspec, (uint32_t)n_ends, hk.max_align,
                                         c->packed.abs_planes, c->packed.abs_valid, reinterpret_cast<uint8_t*>(tile_any + tiles), tile_any);
             c->packed.abs_ready = (uint32_t)n_ends;
+            c->win2_valid = false;                       // (that kernel does not make the two-bit copy)
         } else {
+            c->win2_valid = true;
             hipLaunchKernelGGL(k_pack_windows, dim3(blocks), dim3(256), 0, c->stream,
-                               b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen, c->wspec);
+                               b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen, c->wspec, c->win2);
         }
         mark(c, "k_pack_windows");
     }
     if (hk.mode == QCAT_MODE_SIMPLE && adapter_only) return set_err(QCAT_ERR_ARG, "simple mode has no adapter templates to vote with");
     if (resume_kit_mask >= 0 && !(use_packed && c->packed.slices_single))
         return set_err(QCAT_ERR_UNSUPPORTED, "the adapter pass of this kit cannot be resumed per kit (table or general kernels)");
-    c->packed.wspec = c->wspec; c->packed.win = c->win;
+    c->packed.wspec = c->wspec; c->packed.win = c->win; c->packed.win2 = c->win2_valid ? c->win2 : nullptr;
     // packed barcode results (kernels_bitslice.inc: k_bs_select_ordered) instead of 8 bytes scattered into every record;
     // debug scans keep the records complete for the traces
     const bool slim = use_packed && !debug && hk.mode != QCAT_MODE_SIMPLE && getenv("QCAT_HIP_NO_SLIM") == nullptr;
