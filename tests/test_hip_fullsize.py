@@ -126,13 +126,26 @@ def check_all_records_across_device_paths(r, recs, cnt, monkeypatch, n_generic=2
     assert diff.size == 0, "default path vs general int32 kernel: %d records differ, first at read %d" % (diff.size, diff[0])
 
 
-def test_config2_one_million_reads_5p_only():
+def kernels_of_last_scan(r):
+    names = (C.c_char_p * 16)()
+    ms = (C.c_float * 16)()
+    return [names[i].decode() for i in range(r.lib.qcat_ctx_last_timing(r.ctx.handle, names, ms, 16))]
+
+
+def test_config2_one_million_reads_5p_only(monkeypatch):
     det = scanner.factory(kit="NBD103/NBD104")
     r = Resident(det, native.ENDS_5P, 1000000, 20260929, 0.08)
     try:
+        r.hip.check(r.lib.qcat_ctx_set_timing(r.ctx.handle, 1))
         recs, cnt = r.scan()
+        # 488 adapter tiles: the medium-batch form of the bit-sliced adapter scan (four-stage plans), 1 M jobs of 12-barcode
+        # sets: the bit-sliced barcode kernels
+        ran = kernels_of_last_scan(r)
+        assert "k_adapter_bitslice" in ran and "k_barcode_bitslice" in ran, ran
+        r.hip.check(r.lib.qcat_ctx_set_timing(r.ctx.handle, 0))
         assert cnt[:13].sum() == r.n and cnt[13:15].sum() == r.n and cnt[15] == 0
         assert np.array_equal(cnt, histogram_from_records(r.desc, det.layouts, recs))
+        check_all_records_across_device_paths(r, recs, cnt, monkeypatch)
         recs2, cnt2 = r.scan()
         assert recs2.tobytes() == recs.tobytes() and np.array_equal(cnt, cnt2)          # idempotence
         check_sample_against_oracle(r, recs, 3000, np.random.default_rng(1))
@@ -146,6 +159,24 @@ def test_config2_one_million_reads_5p_only():
         sub_o = np.ascontiguousarray(offs[a:b + 1] - offs[a])
         sub = r.ctx.scan(r.kit, sub_b, sub_o)
         assert sub.tobytes() == recs[a:b].tobytes()
+    finally:
+        r.close()
+
+
+def test_medium_batch_takes_the_bit_sliced_barcode_kernels_by_default(monkeypatch):
+    """120 k PBC096 reads = 240 k jobs: above the point where the bit-sliced barcode kernels pay for a 96-barcode set
+    (70 000 + 3 500 000 / 96 jobs), far below a super-tile per CU -- the batch size of the host pipeline's chunks.  The
+    default path must take them, and every record must equal the binary16 and the general kernels' (+ an oracle sample)."""
+    det = scanner.factory(kit="PBC096")
+    r = Resident(det, native.ENDS_BOTH, 120000, 20261001, 0.08)
+    try:
+        r.hip.check(r.lib.qcat_ctx_set_timing(r.ctx.handle, 1))
+        recs, cnt = r.scan()
+        assert "k_barcode_bitslice" in kernels_of_last_scan(r)
+        r.hip.check(r.lib.qcat_ctx_set_timing(r.ctx.handle, 0))
+        assert np.array_equal(cnt, histogram_from_records(r.desc, det.layouts, recs))
+        check_sample_against_oracle(r, recs, 3000, np.random.default_rng(7))
+        check_all_records_across_device_paths(r, recs, cnt, monkeypatch, n_generic=120000)
     finally:
         r.close()
 
