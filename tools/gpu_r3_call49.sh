@@ -10,5 +10,5 @@ d = json.load(open(sys.argv[1])); k = d['roofline']['kernels_avg_ms']
 print(sys.argv[2], round(d['value'] / 1e6, 2), d['ms_per_step'], {x: round(v, 3) for x, v in k.items() if v > 0.05})
 PY
 done; done
-for n in 4000 50000; do timeout 300 python bench.py --workload config3 --reads $n --no-host-inclusive --no-cpu-baseline 2>/dev/null | python -c "
+for n in 50000; do timeout 300 python bench.py --workload config3 --reads $n --no-host-inclusive --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('c3', $n, d['value'], d['ms_per_step'], d['roofline']['kernels_avg_ms'].get('k_job_sort'))"; done
