@@ -84,3 +84,41 @@ def test_config1_readme_summary_shape():
     bars = [l.split()[0] for l in log[log.index([x for x in log if x.startswith("Barcodes detected")][0]) + 1:] if l.split()]
     assert set(b for b in bars if b.startswith("barcode")) == {"barcode01"}
     assert sorted(run["files"]) == ["barcode01.fastq", "none.fastq"]
+
+
+def test_native_writers_to_a_file_a_pipe_and_an_append_descriptor(tmp_path):
+    """The native writers place their pieces with pwrite when the descriptor has a position and fall back to ordered
+    write() otherwise (csrc/fastq_host.inc): the TSV of one file through `> file`, through a pipe and through `>> file`
+    (behind a line that is already there) must be the same bytes as the Python loop's (QCAT_AMD_NO_NATIVE_FASTQ=1)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "golden", "data", "nbd103.fastq")
+    big = str(tmp_path / "big.fastq")
+    with open(src, "rb") as fh:
+        one = fh.read()
+    with open(big, "wb") as fh:
+        for _ in range(40):                                  # (several writer blocks' worth of reads would need 16 k; the paths are the same)
+            fh.write(one)
+    cmd = [sys.executable, "-m", "qcat_amd.cli", "-f", big, "--tsv", "-k", "NBD103/NBD104"]
+    env = dict(os.environ, PYTHONPATH=root)
+
+    def run(extra_env, stdout):
+        subprocess.check_call(cmd, cwd=root, env=dict(env, **extra_env), stdout=stdout, stderr=subprocess.DEVNULL)
+
+    with open(tmp_path / "direct.tsv", "wb") as fh:
+        run({}, fh)
+    with open(tmp_path / "python.tsv", "wb") as fh:
+        run({"QCAT_AMD_NO_NATIVE_FASTQ": "1"}, fh)
+    p = subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    piped = p.stdout.read()
+    assert p.wait() == 0
+    with open(tmp_path / "append.tsv", "wb") as fh:
+        fh.write(b"a line that was there\n")
+    with open(tmp_path / "append.tsv", "ab") as fh:
+        run({}, fh)
+    want = (tmp_path / "python.tsv").read_bytes()
+    assert want.count(b"\n") > 100
+    assert (tmp_path / "direct.tsv").read_bytes() == want
+    assert piped == want
+    assert (tmp_path / "append.tsv").read_bytes() == b"a line that was there\n" + want
