@@ -23,7 +23,7 @@ with the kernel's average duration measured by HIP events on the library's own s
 `cpu_baseline` times the CPU oracle (a port, not the reference: parasail is absent) on a bounded
 sample of the same reads on the host cores of this box (rank 0, at every N: the other ranks wait at
 the final barrier).  `valu_issue` is the VALU view of the DP phases from COUNTERS, not from a model:
-SQ_INSTS_VALU per launch (profiles/r03_pmc.json, rocprofv3 --pmc on this workload) x 2 issue cycles /
+SQ_INSTS_VALU per launch (the newest profiles/r0N_pmc.json, rocprofv3 --pmc on this workload; replayed with a staleness guard) x 2 issue cycles /
 (1024 SIMDs x the clock GRBM_GUI_ACTIVE measured x the phase time measured live in this run).
 
     python bench.py --workload api4000     # the reference driver's own call shape: detect_barcode_batch on
@@ -100,7 +100,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inclusive", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=4.0,
+                    help="CPU time of the oracle sample (cpu_baseline + parity); short by default so that the GPU work is not a\n"
+                         "sliver of the run the driver's gpu_busy samples see")
     ap.add_argument("--batch", type=int, default=4000, help="api4000: reads per detect_barcode_batch call (cli.py:500)")
     a = ap.parse_args()
     if a.gpus < 1:
@@ -212,17 +214,7 @@ def main():
         avg = {k: float(np.mean(v)) for k, v in kernel_ms.items()}
         compute = {k: v for k, v in avg.items() if not k.startswith("rccl")}
         dom = max(compute, key=compute.get) if compute else None
-        traffic = traffic_src = None
-        for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", tname)) as fh:
-                    tj = json.load(fh).get("config3" if a.workload == "config4" else a.workload)
-                if tj and dom and dom in tj["kernel"]:
-                    traffic = int(tj["bytes"] * (a.reads / float(tj["reads_per_launch"])))
-                    traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, scaled to this launch size)" % tname
-                    break
-            except (IOError, ValueError, KeyError):
-                continue
+        traffic, traffic_src = replayed_traffic(a, dom, avg)
         roof = None
         if dom:
             achieved = a.reads * bytes_per_read / (avg[dom] * 1e-3) / 1e9
@@ -372,21 +364,73 @@ def host_inclusive(a, hip, lib, ctx, kit, cfg, ends, batch, sp, n_bases, recs, c
                     "host-bound (DESIGN.md section 4)" % (int(ho[n]) / 1e6, up / 1e6, n * 24 / 1e6)}
 
 
-def valu_issue(a, avg):
+STALE_TOLERANCE = 0.15
+
+
+def newest_profile(suffix):
+    """profiles/r0N_<suffix> of the latest round that has one"""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)):
+        m = re.match(r"r(\d\d)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
+def stale_reason(rec, mark, live_ms):
+    """Counters are REPLAYED from a committed rocprofv3 pass (the driver's run collects none): the pass says at which commit
+    and at what duration of the mark it was taken, and a live duration more than 15 % off means the kernels are no longer
+    the ones that were counted -- the figure is dropped then, with the reason, instead of being scaled into a wrong one."""
+    ref = (rec.get("mark_ms") or {}).get(mark)
+    if ref is None:
+        return None                     # (files of rounds 1-3 carry no durations: nothing to compare with)
+    if ref <= 0 or abs(live_ms - ref) > STALE_TOLERANCE * ref:
+        return "stale: %s ran %.4f ms per launch when the counters were taken (commit %s), %.4f ms now" % (
+            mark, ref, rec.get("commit", "?"), live_ms)
+    return None
+
+
+def replayed_traffic(a, dom, avg, path=None):
+    wl = "config3" if a.workload == "config4" else a.workload
+    path = path or newest_profile("traffic.json")
+    if not path or not dom:
+        return None, None
+    try:
+        with open(path) as fh:
+            tj = json.load(fh).get(wl)
+    except (IOError, ValueError):
+        return None, None
+    if not tj or dom not in tj.get("kernel", ""):
+        return None, None
+    scale = a.reads / float(tj["reads_per_launch"])
+    why = stale_reason({"mark_ms": {dom: tj["mark_ms"] * scale} if tj.get("mark_ms") is not None else None, "commit": tj.get("commit")}, dom, avg[dom])
+    rel = os.path.relpath(path, ROOT)
+    if why:
+        return None, "%s not replayed -- %s" % (rel, why)
+    return int(tj["bytes"] * scale), "%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE at commit %s, scaled to this launch size)" % (rel, tj.get("commit", "?"))
+
+
+def valu_issue(a, avg, path=None):
     """VALU-issue utilisation of the DP phases from hardware counters: instructions issued (SQ_INSTS_VALU, summed over
     the kernels of a timing mark, per launch, from the committed PMC pass of this workload, scaled to this launch's
     read count) x 2 cycles -- the fastest a wave64 VALU instruction issues on a CDNA SIMD -- / (1024 SIMDs x effective
-    clock x the mark's duration measured live in this run).  <= 1 by construction; no instruction-mix model."""
+    clock x the mark's duration measured live in this run).  No instruction-mix model and NO clamp: a fraction above 1
+    cannot be a utilisation, so it is printed as null with the reason (a counter file that no longer belongs to the
+    kernels), and so is a mark whose live duration is more than 15 % away from the one the counters were taken at."""
     wl = "config3" if a.workload == "config4" else a.workload
+    path = path or newest_profile("pmc.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as fh:
+        with open(path) as fh:
             pj = json.load(fh).get(wl)
-    except (IOError, ValueError):
+    except (IOError, ValueError, TypeError):
         pj = None
     if not pj:
         return None
     clock = float(pj["clock_ghz"]) * 1e9
-    out = {"source": "profiles/r03_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE, tools/update_pmc.py)",
+    out = {"source": "%s (rocprofv3 --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE at commit %s, tools/update_pmc.py), replayed: "
+                     "durations are measured live" % (os.path.relpath(path, ROOT), pj.get("commit", "?")),
            "clock_ghz": pj["clock_ghz"], "simds": 1024, "issue_cycles_per_inst": 2, "marks": {}}
     scale = a.reads / float(pj["reads_per_launch"])
     for mark, m in pj["marks"].items():
@@ -394,8 +438,17 @@ def valu_issue(a, avg):
             continue
         insts = m["insts_valu"] * scale
         util = insts * 2.0 / (1024.0 * clock * avg[mark] * 1e-3)
-        out["marks"][mark] = {"insts_valu_per_launch": int(insts), "ms": round(avg[mark], 4), "issue_util": round(min(util, 1.0), 4),
-                              "issue_util_at_2p4ghz": round(min(insts * 2.0 / (1024.0 * 2.4e9 * avg[mark] * 1e-3), 1.0), 4)}
+        util24 = insts * 2.0 / (1024.0 * 2.4e9 * avg[mark] * 1e-3)
+        rec = {"insts_valu_per_launch": int(insts), "ms": round(avg[mark], 4)}
+        why = stale_reason({"mark_ms": {k: v * scale for k, v in pj["mark_ms"].items()} if pj.get("mark_ms") else None,
+                            "commit": pj.get("commit")}, mark, avg[mark])
+        if why is None and (util > 1.0 or util24 > 1.0):
+            why = "impossible: %d instructions x 2 cycles do not fit %.4f ms on 1024 SIMDs (%.3f of the issue peak) -- the counter file does not belong to these kernels" % (int(insts), avg[mark], util)
+        if why:
+            rec.update({"issue_util": None, "issue_util_at_2p4ghz": None, "reason": why})
+        else:
+            rec.update({"issue_util": round(util, 4), "issue_util_at_2p4ghz": round(util24, 4)})
+        out["marks"][mark] = rec
     return out
 
 

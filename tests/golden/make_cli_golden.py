@@ -2,8 +2,8 @@
 """Generate tests/golden/cli_golden.json: outputs of the UNMODIFIED reference driver
 (`qcat.cli.qcat_cli`, /root/reference, read-only) over the four shipped FASTQ files, for the
 host-pipeline parity tests.  Dev tool for the authoring container; see
-make_golden.py for what is real (all of qcat's Python) and what is a stand-in (parasail -> oracle
-DP, Bio parsers)."""
+make_golden.py for what is real (all of qcat's Python) and what is a stand-in (parasail -> the
+independent scalar DP tests/golden/sg_independent.py, which shares no code with the oracle; Bio -> two parsers)."""
 import contextlib
 import hashlib
 import io

@@ -557,8 +557,9 @@ def test_bit_sliced_adapter_kernels_equal_the_binary16_kernels_and_the_oracle(mo
     binary16 kernels of the same kit the 128-end tiles that hold anything else.  A debug scan of a mixed batch (plain
     reads, reads with N / IUPAC letters / lower case, reads shorter than two windows, degenerate reads) compares the
     per-template raw score AND end_query of every window (trace), every per-barcode row and the records with the
-    oracle -- with the path forced, and with it switched off.  Templates without a plan (too long for two stages: the
-    98-column template of the dual kit) simply stay on the binary16 kernels beside the ones that have one."""
+    oracle -- with the path forced, and with it switched off.  Both templates of the dual kit have a plan (the
+    98-column one compiles to 51 + 47 columns, QAB_T13); a template without one would simply stay on the binary16 kernels
+    beside the ones that have one."""
     det = scanner.factory(mode=mode, kit=kit)
     t5 = len(det.layouts) - 1 if kit else (3 if mode == "epi2me" else 1)
     t3 = 0 if len(det.layouts) > 1 else -1
@@ -586,7 +587,7 @@ def test_bit_sliced_adapter_kernels_equal_the_binary16_kernels_and_the_oracle(mo
     o_recs, o_cnt, o_traces, o_rows = oracle_lib.scan(d, reads, counts=True, trace=True, rows=True, threads=16)
     bases, offsets = native.pack_reads(reads)
     lib = native.HipLibrary.get().lib
-    has_plan = True                                             # (dual kit: its 83-column template has one, the 98-column one not)
+    has_plan = True                                             # (every built-in selection here has a plan for each of its templates)
     # forced with the two-stage plans everywhere, forced with the four-stage plans where a template has one (the
     # medium-batch form, k_adapter_ms), switched off
     for variant in ("forced", "forced4", "off"):

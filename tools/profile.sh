@@ -9,6 +9,8 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cmd="python $R/bench.py --workload $wl --no-cpu-baseline --no-host-inclusive $*"
+# 0) the same command without a profiler: the durations of the timing marks the counters will be replayed against (bench.py: stale_reason)
+$cmd > $R/$out/bench_plain.log 2>/dev/null
 rocprofv3 --kernel-trace --stats -d /tmp/rp_$tag/trace -o trace --output-format csv -- $cmd > $R/$out/bench_under_trace.log 2>&1
 find /tmp/rp_$tag/trace -name "*kernel_stats.csv" -exec cp {} $R/$out/kernel_stats.csv \;
 i=0

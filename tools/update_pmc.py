@@ -48,6 +48,33 @@ def per_kernel(fn, counter):
     return per
 
 
+
+def stamp(d):
+    """what a replayed figure is checked against (bench.py: stale_reason): the commit the profiled build was made from (this
+    tool runs in the authoring container right after the gpurun call; --commit overrides) and the per-launch duration of
+    every timing mark in the un-profiled run of the same command (bench_plain.log, tools/profile.sh step 0)"""
+    import subprocess
+    commit = None
+    for a in sys.argv:
+        if a.startswith("--commit="):
+            commit = a.split("=", 1)[1]
+    if commit is None:
+        try:
+            commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
+            if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "qcat_amd", "bench.py"]).decode().strip():
+                commit += "+uncommitted"
+        except Exception:
+            commit = "unknown"
+    marks = None
+    try:
+        with open(os.path.join(d, "bench_plain.log")) as fh:
+            line = [l for l in fh.read().splitlines() if l.startswith("{")][-1]
+        marks = json.loads(line)["roofline"]["kernels_avg_ms"]
+    except (IOError, IndexError, KeyError, ValueError, TypeError):
+        pass
+    return commit, marks
+
+
 def main():
     tag = sys.argv[1]
     out = {"_comment": "VALU instructions issued per scan (SQ_INSTS_VALU, summed over the kernels inside a timing mark, "
@@ -55,7 +82,7 @@ def main():
            "than 1 ms) from rocprofv3 --pmc passes of `bench.py --workload <w>` (tools/profile.sh; per-dispatch averages in "
            "profiles/%s_*/summary.txt).  bench.py: issue utilisation = insts_valu x 2 cycles / (1024 SIMDs x clock x mark "
            "time measured live)." % tag}
-    for arg in sys.argv[2:]:
+    for arg in [x for x in sys.argv[2:] if not x.startswith("--")]:
         wl, d = arg.split("=")
         reads = 1000000
         if ":" in d:
@@ -91,7 +118,8 @@ def main():
                     clock = None
         except IOError:
             pass
-        out[wl] = {"reads_per_launch": reads, "scans_in_run": n_scans,
+        commit, mark_ms = stamp(d)
+        out[wl] = {"reads_per_launch": reads, "scans_in_run": n_scans, "commit": commit, "mark_ms": mark_ms,
                    "clock_ghz": round(clock, 4) if clock else 2.4,
                    "clock_source": "GRBM_GUI_ACTIVE (sum over 8 XCDs) / 8 / dispatch duration, kernels > 1 ms" if clock else "nominal 2.4 GHz (no GRBM pass)",
                    "marks": {m: {"insts_valu": int(v["insts_valu"]), "kernels": v["kernels"]} for m, v in sorted(marks.items())}}

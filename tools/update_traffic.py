@@ -10,7 +10,35 @@ out = {"_comment": "HBM traffic of the dominant kernel per launch, from rocprofv
        "passes, tools/profile.sh; per-dispatch averages in profiles/%s_*/summary.txt). bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: "
        "FETCH_SIZE/WRITE_SIZE are in KiB and gfx950's FETCH_SIZE reports half of a wide coalesced read stream "
        "(MI355X_MICROARCH.md, HBM section); all kernels of the dominant timing mark that ran in the step are summed (bit-sliced: k_bs_barcode of every family + k_bs_select + k_bs_plan; else the static-letter kernels of every group and the table kernels of every width class)." % tag}
-for arg in sys.argv[2:]:
+
+
+def stamp(d):
+    """what a replayed figure is checked against (bench.py: stale_reason): the commit the profiled build was made from (this
+    tool runs in the authoring container right after the gpurun call; --commit overrides) and the per-launch duration of
+    every timing mark in the un-profiled run of the same command (bench_plain.log, tools/profile.sh step 0)"""
+    import subprocess
+    commit = None
+    for a in sys.argv:
+        if a.startswith("--commit="):
+            commit = a.split("=", 1)[1]
+    if commit is None:
+        try:
+            commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
+            if subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "qcat_amd", "bench.py"]).decode().strip():
+                commit += "+uncommitted"
+        except Exception:
+            commit = "unknown"
+    marks = None
+    try:
+        with open(os.path.join(d, "bench_plain.log")) as fh:
+            line = [l for l in fh.read().splitlines() if l.startswith("{")][-1]
+        marks = json.loads(line)["roofline"]["kernels_avg_ms"]
+    except (IOError, IndexError, KeyError, ValueError, TypeError):
+        pass
+    return commit, marks
+
+
+for arg in [x for x in sys.argv[2:] if not x.startswith("--")]:
     wl, d = arg.split("=")
     reads = 1000000
     if ":" in d:
@@ -28,7 +56,9 @@ for arg in sys.argv[2:]:
                 if any(p in row["Kernel_Name"] for p in pats) and row["Counter_Name"] == name:
                     per[row["Kernel_Name"]].append(float(row["Counter_Value"]))
         tot[name] = sum(sum(v) / len(v) for v in per.values())
-    out[wl] = {"kernel": "k_barcode_bitslice (k_bs_barcode + k_bs_select + k_bs_plan)" if bitsliced else "k_barcode_static+k_barcode_packed",
+    commit, marks = stamp(d)
+    dom_mark = "k_barcode_bitslice" if bitsliced else "k_barcode_static"
+    out[wl] = {"commit": commit, "mark_ms": (marks or {}).get(dom_mark), "kernel": "k_barcode_bitslice (k_bs_barcode + k_bs_select + k_bs_plan)" if bitsliced else "k_barcode_static+k_barcode_packed",
                "reads_per_launch": reads, "fetch_size_kib": round(tot["FETCH_SIZE"], 1),
                "write_size_kib": round(tot["WRITE_SIZE"], 1), "bytes": int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024)}
 with open(os.path.join(ROOT, "profiles", tag + "_traffic.json"), "w") as fh:
