@@ -49,7 +49,8 @@ typedef enum qcat_status {
     QCAT_ERR_ARG = -1,          /* bad descriptor / argument (RuntimeError on the Python side) */
     QCAT_ERR_UNSUPPORTED = -2,  /* valid qcat configuration the device path does not cover  */
     QCAT_ERR_DEVICE = -3,       /* HIP runtime failure / no device                           */
-    QCAT_ERR_NOMEM = -4
+    QCAT_ERR_NOMEM = -4,
+    QCAT_ERR_IO = -5            /* writing an output of qcat_fastq_demux failed (errno text in qcat_last_error) */
 } qcat_status;
 
 /* Scanner mode: which `scan()` the batch entry points reproduce. */
@@ -275,9 +276,22 @@ int  qcat_scan_sequences(qcat_ctx* ctx, const qcat_kit* kit,
  * (qcat/scanner_base.py:191-220), align_adapter_identity (:144-188), find_highest_scoring_barcode (:108-117): n independent
  * semi-global alignments of query i = queries[q_offsets[i] .. q_offsets[i+1]) against target i (ASCII, any case; targets
  * up to QCAT_MAX_TEMPLATE_LEN letters), affine gaps, `matrix`[target code * 7 + query code] over the codes above.
- * score / end_query / end_ref follow rule R1 (oracle/qcat_oracle.c:100-108); with_stats != 0 also fills `matches` (exact
- * letter matches) and `length` (alignment columns) along one optimal path -- parity with parasail unpinned for these two
- * (no scanner path consumes them, scanner_base.py:141).  An empty query or target gives end_query = end_ref = -1. */
+ * score / end_query / end_ref follow rule R1 (oracle/qcat_oracle.c:100-108); with_stats != 0 also fills `matches` and
+ * `length` (alignment columns) along ONE optimal path, chosen by the rule `with_stats` names (QCAT_STATS_*):
+ *   QCAT_STATS_PARASAIL6  ties: diagonal, then the gap that consumes a QUERY letter (parasail's F), then the gap that
+ *                         consumes a target letter (E); a match = equal MAPPED codes over the alphabet ATGCNX + '*' (two
+ *                         different letters outside the alphabet both map to '*' and count) -- the adapter matrix,
+ *                         align_adapter_identity (qcat/scanner_base.py:168-172, config.py:245);
+ *   QCAT_STATS_PARASAIL5  the same over ATGCN + '*' (X maps to '*' too) -- the barcode matrix, find_highest_scoring_barcode
+ *                         with compute_identity (scanner_base.py:105-117, config.py:26);
+ *   QCAT_STATS_ROUND3     round 3's order (diagonal, E, F; a match = the same letter) -- kept for comparison.
+ * The PARASAIL rules restate parasail 2.x's *_stats_striped_* kernels as recalled (case1 = H == H_dag, case2 = H == F,
+ * HM = case1 ? H_dagM + match : case2 ? FM : EM; a gap is opened only when strictly better than extended); PARITY WITH
+ * PARASAIL IS UNPINNED for these two numbers -- parasail is absent from this image and no reference test holds them (no
+ * scanner path consumes them, scanner_base.py:141).  One switch, three implementations: this kernel (k_sg_align),
+ * oracle/qcat_oracle.c qo_sg_stats, tests/golden/sg_independent.py sg_stats.  An empty query or target gives
+ * end_query = end_ref = -1. */
+enum { QCAT_STATS_NONE = 0, QCAT_STATS_PARASAIL6 = 1, QCAT_STATS_PARASAIL5 = 3, QCAT_STATS_ROUND3 = 5 };
 typedef struct qcat_alignment { int32_t score, end_query, end_ref, matches, length; } qcat_alignment;
 int  qcat_sg_align(qcat_ctx* ctx, const uint8_t* queries, const uint64_t* q_offsets,
                    const uint8_t* targets, const uint64_t* t_offsets, uint32_t n,

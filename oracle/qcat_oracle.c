@@ -128,16 +128,25 @@ int qo_sg(const char* s1, int L, const char* s2, int M, int open, int extend,
 /* ------------------------------------------------------------------------------------------
  * parasail.sg_stats_striped_32 as called at qcat/scanner_base.py:168-172 (align_adapter_identity) and :108-117
  * (find_highest_scoring_barcode with compute_identity): the alignment of qo_sg plus the number of exact matches and of
- * alignment columns along ONE optimal path.  PARITY UNPINNED for `matches` / `length`: which of several optimal paths
- * parasail walks is not documented and parasail is absent here; the tie order restated is the one of
- * tests/golden/sg_independent.py (diagonal first, then the gap that consumes a target letter, then the gap that consumes a
- * query letter; an opened gap wins over an extended one only when strictly better).  Nothing on any scanner path
- * consumes the two numbers (scanner_base.py:141 returns the score in their place).
+ * alignment columns along ONE optimal path, chosen by `rule` (include/qcat_hip.h QCAT_STATS_*; ONE switch shared with the
+ * device kernel k_sg_align and tests/golden/sg_independent.py sg_stats):
+ *   PARASAIL6 / PARASAIL5 -- parasail 2.x's *_stats_striped_* kernels as recalled: H = max(H_dag, E, F), then
+ *       case1 = (H == H_dag), case2 = (H == F), HM = case1 ? H_dagM + match : (case2 ? FM : EM): on ties the diagonal, then
+ *       F (the gap that consumes a QUERY letter), then E; `match` = equality of the MAPPED codes (alphabet ATGCNX + '*',
+ *       or ATGCN + '*' where X maps to '*' as well: the barcode matrix), so two different letters outside the alphabet
+ *       count as a match; a gap is opened only when strictly better than extended (case = opn > ext);
+ *   ROUND3 -- diagonal, E, F and "the same letter" (what round 3 shipped).
+ * PARITY UNPINNED for `matches` / `length` under every rule: parasail is absent here and no reference test holds the two
+ * numbers.  Nothing on any scanner path consumes them (scanner_base.py:141 returns the score in their place).
  * ---------------------------------------------------------------------------------------- */
 typedef struct qo_stats { int32_t score, end_query, end_ref, matches, length; } qo_stats;
 
-int qo_sg_stats(const char* s1, int L, const char* s2, int M, int open, int extend, const int8_t* mat, qo_stats* out) {
+int qo_sg_stats_rule(const char* s1, int L, const char* s2, int M, int open, int extend, const int8_t* mat, int rule, qo_stats* out) {
     qo_init_tables();
+    if (rule != QCAT_STATS_PARASAIL6 && rule != QCAT_STATS_PARASAIL5 && rule != QCAT_STATS_ROUND3) {
+        snprintf(qo_err, sizeof qo_err, "qo_sg_stats: unknown rule %d", rule);
+        return QCAT_ERR_ARG;
+    }
     if (L <= 0 || M <= 0 || L > QO_MAXW || M > QCAT_MAX_TEMPLATE_LEN) {
         snprintf(qo_err, sizeof qo_err, "qo_sg_stats: bad lengths %d x %d", L, M);
         return QCAT_ERR_ARG;
@@ -162,11 +171,18 @@ int qo_sg_stats(const char* s1, int L, const char* s2, int M, int open, int exte
             if (H[j] - open > F[j] - extend) { f = H[j] - open; fm = HM[j]; fl = HL[j] + 1; }
             else { f = F[j] - extend; fm = FM[j]; fl = FL[j] + 1; }
             int32_t h = diag + mat[tc * 7 + qc];
-            int32_t hm = dm + ((qo_code_of[(uint8_t)s1[i - 1]] == qo_code_of[(uint8_t)s2[j - 1]] &&
-                                ((s1[i - 1] | 0x20) == (s2[j - 1] | 0x20))) ? 1 : 0);
+            const int qm = (rule == QCAT_STATS_PARASAIL5 && qc == QCAT_CODE_X) ? QCAT_CODE_OTHER : qc;
+            const int tm = (rule == QCAT_STATS_PARASAIL5 && tc == QCAT_CODE_X) ? QCAT_CODE_OTHER : tc;
+            const int same = rule == QCAT_STATS_ROUND3 ? (qc == tc && ((s1[i - 1] | 0x20) == (s2[j - 1] | 0x20))) : (qm == tm);
+            int32_t hm = dm + (same ? 1 : 0);
             int32_t hl = dl + 1;
-            if (e > h) { h = e; hm = em; hl = el; }
-            if (f > h) { h = f; hm = fm; hl = fl; }
+            if (rule == QCAT_STATS_ROUND3) {
+                if (e > h) { h = e; hm = em; hl = el; }
+                if (f > h) { h = f; hm = fm; hl = fl; }
+            } else {
+                if (f > h) { h = f; hm = fm; hl = fl; }
+                if (e > h) { h = e; hm = em; hl = el; }
+            }
             diag = H[j]; dm = HM[j]; dl = HL[j];
             H[j] = h; HM[j] = hm; HL[j] = hl; F[j] = f; FM[j] = fm; FL[j] = fl;
             hleft = h; hlm = hm; hll = hl;
@@ -179,6 +195,10 @@ int qo_sg_stats(const char* s1, int L, const char* s2, int M, int open, int exte
     if (cmax > score || (cmax == score && end_r == M - 1)) { score = cmax; end_r = M - 1; end_q = cfirst - 1; mm = cm; ll = cl; }
     out->score = score; out->end_query = end_q; out->end_ref = end_r; out->matches = mm; out->length = ll;
     return 0;
+}
+
+int qo_sg_stats(const char* s1, int L, const char* s2, int M, int open, int extend, const int8_t* mat, qo_stats* out) {
+    return qo_sg_stats_rule(s1, L, s2, M, open, extend, mat, QCAT_STATS_PARASAIL6, out);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -326,16 +326,22 @@ def _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_
         if cnt:
             key = layouts[t - 1].kit if t > 0 else "none"
             adapter_dist[key] = adapter_dist.get(key, 0) + cnt
-    called = b >= 0
+    dual = detector._native_mode == "dual"
+    # the same guard as the native writers (fastq_host.inc): a call needs every index inside its table -- a record with a
+    # barcode but no adapter, or a dual record without its second barcode, counts as "none" instead of giving bincount a
+    # negative key
+    called = (b >= 0) & (a >= 0)
+    b2 = recs["barcode2_idx"][keep].astype(np.int64) if dual else None
+    if dual:
+        called &= b2 >= 0
     n_none = int(len(b) - int(called.sum()))
     if n_none:
         barcode_dist["none"] = n_none
-    dual = detector._native_mode == "dual"
     w0 = 1 + max(len(l.get_barcode_set(0) or ()) for l in layouts)
     w1 = 1 + (max(len(l.get_barcode_set(1) or ()) for l in layouts) if dual else 0)
     keys = (a[called] * w0 + b[called]) * w1
     if dual:
-        keys = keys + recs["barcode2_idx"][keep].astype(np.int64)[called]
+        keys = keys + b2[called]
     for k, cnt in enumerate(np.bincount(keys, minlength=1).tolist()):
         if not cnt:
             continue

@@ -1379,6 +1379,8 @@ extern "C" int qcat_sg_align(qcat_ctx* c, const uint8_t* queries, const uint64_t
     if (!c || !q_offsets || !t_offsets || !matrix || !out) return set_err(QCAT_ERR_ARG, "qcat_sg_align: null argument");
     if (n == 0) return 0;
     if (gap_open < 0 || gap_extend < 0) return set_err(QCAT_ERR_ARG, "qcat_sg_align: negative gap cost");
+    if (with_stats != QCAT_STATS_NONE && with_stats != QCAT_STATS_PARASAIL6 && with_stats != QCAT_STATS_PARASAIL5 && with_stats != QCAT_STATS_ROUND3)
+        return set_err(QCAT_ERR_ARG, "qcat_sg_align: with_stats must be one of QCAT_STATS_*");
     for (uint32_t i = 0; i < n; ++i) {
         if (q_offsets[i + 1] < q_offsets[i] || t_offsets[i + 1] < t_offsets[i]) return set_err(QCAT_ERR_ARG, "offsets must be non-decreasing");
         if (t_offsets[i + 1] - t_offsets[i] > (uint64_t)MAX_TLEN) return set_err(QCAT_ERR_UNSUPPORTED, "qcat_sg_align: target longer than QCAT_MAX_TEMPLATE_LEN");
@@ -1399,7 +1401,7 @@ extern "C" int qcat_sg_align(qcat_ctx* c, const uint8_t* queries, const uint64_t
     SgMatrix m;
     memcpy(m.m, matrix, 49);
     hipLaunchKernelGGL(k_sg_align, dim3(blocks), dim3(GEN_THREADS), 0, c->stream, dq.as<uint8_t>(), dqo.as<uint64_t>(), dt.as<uint8_t>(),
-                       dto.as<uint64_t>(), n, (int)gap_open, (int)gap_extend, m, with_stats ? 1 : 0, dscr.as<int32_t>(), dout.as<qcat_alignment>());
+                       dto.as<uint64_t>(), n, (int)gap_open, (int)gap_extend, m, (int)with_stats, dscr.as<int32_t>(), dout.as<qcat_alignment>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * sizeof(qcat_alignment), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

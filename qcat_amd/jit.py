@@ -237,11 +237,11 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
                 s1, s0 = _bs_shared_words(targets[0], rev, pre)
                 parts.append("struct QBSJ_%d {\n    static constexpr int C = %d, KERNEL = QCAT_JIT_BASE + %d, PRE = %d;\n"
                              "    static constexpr unsigned S1 = 0x%Xu, S0 = 0x%Xu;\n"
-                             "    static __device__ __forceinline__ void rows(int kase, const uint4* __restrict__ s_rows, int L, int lane, "
-                             "bool shared, u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n" % (g, own, g, pre, s1, s0))
+                             "    static __device__ __forceinline__ void rows(int kase, const BsRowArgs& ra, "
+                             "u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n" % (g, own, g, pre, s1, s0))
                 for b, tg in enumerate(targets):
                     w1, w0 = _bs_words(tg, rev, pre)
-                    parts.append("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(s_rows, L, lane, shared, h1, h0, f); break;\n" % (b, w1, w0))
+                    parts.append("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(ra, h1, h0, f); break;\n" % (b, w1, w0))
                 parts.append("        default: break;\n        }\n    }\n};\n")
                 entry.append('extern "C" __global__ void __launch_bounds__(qk::BS_WAVES * 64) '
                              "qj_bs_%d(qk::BsArgs a) { qk::bs_barcode_body<qk::QBSJ_%d>(a); }\n" % (g, g))

@@ -316,6 +316,8 @@ class HipLibrary(object):
     def check(self, rc):
         if rc != 0:
             msg = self.lib.qcat_last_error()
+            if rc == -5:                                  # QCAT_ERR_IO: an output of qcat_fastq_demux could not be written
+                raise IOError("qcat_hip: {}".format((msg or b"").decode("utf-8", "replace")))
             raise RuntimeError("qcat_hip error {}: {}".format(rc, (msg or b"").decode("utf-8", "replace")))
 
 
@@ -526,9 +528,14 @@ class NativeContext(object):
 ALIGN_DTYPE = np.dtype([("score", "<i4"), ("end_query", "<i4"), ("end_ref", "<i4"), ("matches", "<i4"), ("length", "<i4")])
 
 
+# which optimal path `matches` / `length` follow (include/qcat_hip.h QCAT_STATS_*; parity with parasail unpinned)
+STATS_NONE, STATS_PARASAIL6, STATS_PARASAIL5, STATS_ROUND3 = 0, 1, 3, 5
+
+
 def sg_align(ctx, queries, targets, gap_open, gap_extend, table, with_stats=False):
     """qcat_sg_align: semi-global alignments of queries[i] against targets[i] on the device (parasail_sg /
-    parasail_sg_stat of the reference's helpers); returns an ALIGN_DTYPE array."""
+    parasail_sg_stat of the reference's helpers); returns an ALIGN_DTYPE array.  ``with_stats``: False, True (the
+    adapter matrix's alphabet, STATS_PARASAIL6) or one of STATS_*."""
     n = len(queries)
     out = np.zeros(n, dtype=ALIGN_DTYPE)
     if n == 0:
@@ -538,7 +545,8 @@ def sg_align(ctx, queries, targets, gap_open, gap_extend, table, with_stats=Fals
     t = np.ascontiguousarray(np.asarray(table, dtype=np.int8).reshape(-1))
     hip = HipLibrary.get()
     hip.check(hip.lib.qcat_sg_align(ctx.handle, qb.ctypes.data, qo.ctypes.data, tb.ctypes.data, to.ctypes.data, n,
-                                    int(gap_open), int(gap_extend), t.ctypes.data, 1 if with_stats else 0, out.ctypes.data))
+                                    int(gap_open), int(gap_extend), t.ctypes.data,
+                                    STATS_PARASAIL6 if with_stats is True else int(with_stats or 0), out.ctypes.data))
     return out
 
 

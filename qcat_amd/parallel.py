@@ -21,6 +21,7 @@ from . import native
 
 _MAGIC_REQ = b"QCATRDZV2"
 _MAGIC_REP = b"QCATID002"
+_ACK = b"K"                                   # a rank acknowledges the id it has read: rank 0 counts it then
 _N_CANDIDATE_PORTS = 16
 _NONCE_BYTES = 8
 
@@ -118,13 +119,16 @@ def exchange_id(rank, world_size, make_id, environ=None, timeout=300.0):
                     try:
                         req = _recv_exact(conn, len(_MAGIC_REQ) + _NONCE_BYTES + 8)
                         w, r = struct.unpack("<ii", req[len(_MAGIC_REQ) + _NONCE_BYTES:])
-                        # another job's rank (wrong nonce), a malformed request or a rank that was already
-                        # served gets no id and is not counted
+                        # another job's rank (wrong nonce) or a malformed request gets no id and is not counted
                         if (req[:len(_MAGIC_REQ)] != _MAGIC_REQ or req[len(_MAGIC_REQ):len(_MAGIC_REQ) + _NONCE_BYTES] != nonce
-                                or w != world_size or not (0 < r < world_size) or r in served):
+                                or w != world_size or not (0 < r < world_size)):
                             continue
+                        # a rank counts once (the set) and only when it has acknowledged the id: one whose read of the
+                        # reply failed (socket timeout, reset) asks again and is served again instead of being skipped
+                        # until the deadline
                         conn.sendall(_MAGIC_REP + nonce + struct.pack("<i", len(payload)) + payload)
-                        served.add(r)
+                        if _recv_exact(conn, 1) == _ACK:
+                            served.add(r)
                     except (OSError, ConnectionError, struct.error):
                         continue
         finally:
@@ -141,7 +145,9 @@ def exchange_id(rank, world_size, make_id, environ=None, timeout=300.0):
                     if head[:len(_MAGIC_REP)] != _MAGIC_REP or head[len(_MAGIC_REP):len(_MAGIC_REP) + _NONCE_BYTES] != nonce:
                         continue                             # some other job's server: try the next port
                     (n,) = struct.unpack("<i", head[len(_MAGIC_REP) + _NONCE_BYTES:])
-                    return _recv_exact(conn, n)
+                    got = _recv_exact(conn, n)
+                    conn.sendall(_ACK)
+                    return got
             except (OSError, ConnectionError, struct.error):
                 continue
         time.sleep(0.05)

@@ -94,7 +94,8 @@ def find_highest_scoring_barcode(barcode_region_read, barcode_set, qcat_config, 
     if not barcode_region_read:
         return max_barcode, q_score, max_identity, max_end
     targets = [upstream_context + b.sequence + downstream_context for b in barcode_set]
-    al = _sg([barcode_region_read] * len(targets), targets, 1, 1, qcat_config.matrix_barcode, with_stats=compute_identity)
+    al = _sg([barcode_region_read] * len(targets), targets, 1, 1, qcat_config.matrix_barcode,
+             with_stats=native.STATS_PARASAIL5 if compute_identity else False)      # (the barcode matrix's alphabet is ATGCN)
     max_score = None
     for b, target, a in zip(barcode_set, targets, al):
         score = int(a["score"]) * 100.0 / (1.0 * len(target))
@@ -106,12 +107,13 @@ def find_highest_scoring_barcode(barcode_region_read, barcode_set, qcat_config, 
 def align_adapter_identity(adapter_sequence, adapter_length, read_sequence, barcode_length, qcat_config):
     """``qcat/scanner_base.py:144-188``: the adapter alignment with its identity = matches / (alignment columns - barcode
     length); an alignment that covers less than 85 % of the adapter is discarded ``(None, 0.0)``.  ``matches`` / ``length``
-    follow one optimal path (include/qcat_hip.h, qcat_sg_align: parity with parasail's choice among several optimal paths
-    is unpinned)."""
+    follow one optimal path, chosen as parasail's stats kernels are recalled to choose it (include/qcat_hip.h,
+    QCAT_STATS_PARASAIL6: diagonal, then the gap in the read, then the gap in the adapter; matches over mapped codes --
+    parity with parasail is unpinned)."""
     if not read_sequence or not adapter_sequence:
         return None, 0.0
     a = Alignment(_sg([read_sequence], [adapter_sequence], qcat_config.gap_open, qcat_config.gap_extend, qcat_config.matrix,
-                      with_stats=True)[0])
+                      with_stats=native.STATS_PARASAIL6)[0])
     if a.length < (adapter_length * 0.85):
         return None, 0.0
     return a, float(a.matches) / float(a.length - barcode_length)

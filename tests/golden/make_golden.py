@@ -147,7 +147,7 @@ def install_standins():
                 flat, score = matrix.scorer()
                 key = ("stats", s1, s2, open, extend, matrix.alphabet, flat)
                 if key not in _MEMO:
-                    _MEMO[key] = sg_independent.sg_stats(s1, s2, open, extend, score)
+                    _MEMO[key] = sg_independent.sg_stats(s1, s2, open, extend, score, alphabet=matrix.alphabet)
                 return StatsResult(*_MEMO[key])
 
             sg_stats = sg_stats_striped_32

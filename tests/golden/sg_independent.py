@@ -94,11 +94,27 @@ def sg(s1, s2, gap_open, gap_extend, score):
     return best, end_query, end_ref
 
 
-def sg_stats(s1, s2, gap_open, gap_extend, score):
-    """-> (score, end_query, end_ref, matches, length): the same alignment with the number of exact matches and
-    of alignment columns along ONE optimal path (diagonal preferred over a gap in the target, that over a gap in
-    the query -- parasail's own tie order is not documented here and NOTHING on the scanner paths consumes these
-    two numbers: find_highest_scoring_barcode returns the score in their place, qcat/scanner_base.py:141)."""
+def sg_stats(s1, s2, gap_open, gap_extend, score, alphabet="ATGCNX", rule="parasail"):
+    """-> (score, end_query, end_ref, matches, length): the same alignment with the number of matches and of alignment
+    columns along ONE optimal path.  `rule` is the switch shared with oracle/qcat_oracle.c qo_sg_stats and the device
+    kernel k_sg_align (include/qcat_hip.h QCAT_STATS_*):
+      "parasail" -- parasail 2.x's *_stats_striped_* kernels as recalled: on ties the diagonal, then F (the gap that
+                    consumes a QUERY letter), then E (a target letter); a match = equal MAPPED codes over `alphabet` + '*'
+                    (letters outside the alphabet all map to '*', case-insensitively); a gap is opened only when strictly
+                    better than extended;
+      "round3"   -- diagonal, E, F and "the same letter" (what round 3 shipped).
+    Parity with parasail is UNPINNED for these two numbers (parasail is absent here) and NOTHING on the scanner paths
+    consumes them: find_highest_scoring_barcode returns the score in their place, qcat/scanner_base.py:141."""
+    assert rule in ("parasail", "round3")
+
+    def code(ch):
+        i = alphabet.find(ch.upper())
+        return i if i >= 0 else len(alphabet)
+
+    def same(a, b):
+        if rule == "round3":
+            return a.upper() == b.upper() and "ATGCNX".find(a.upper()) >= 0 or (a.upper() == b.upper())
+        return code(a) == code(b)
     n, m = len(s1), len(s2)
     best, end_query, end_ref = sg(s1, s2, gap_open, gap_extend, score)
     # recompute with statistics carried along (small inputs only: the simple-mode fixtures)
@@ -122,12 +138,18 @@ def sg_stats(s1, s2, gap_open, gap_extend, score):
             else:
                 F[j][i], MF[j][i] = f_ext, (MF[j][i - 1][0], MF[j][i - 1][1] + 1)
             d = H[j - 1][i - 1] + score(s1[i - 1], b)
-            dm = (MH[j - 1][i - 1][0] + (1 if s1[i - 1].upper() == b.upper() else 0), MH[j - 1][i - 1][1] + 1)
+            dm = (MH[j - 1][i - 1][0] + (1 if same(s1[i - 1], b) else 0), MH[j - 1][i - 1][1] + 1)
             h, mh = d, dm
-            if E[j][i] > h:
-                h, mh = E[j][i], ME[j][i]
-            if F[j][i] > h:
-                h, mh = F[j][i], MF[j][i]
+            if rule == "round3":
+                if E[j][i] > h:
+                    h, mh = E[j][i], ME[j][i]
+                if F[j][i] > h:
+                    h, mh = F[j][i], MF[j][i]
+            else:
+                if F[j][i] > h:
+                    h, mh = F[j][i], MF[j][i]
+                if E[j][i] > h:
+                    h, mh = E[j][i], ME[j][i]
             H[j][i], MH[j][i] = h, mh
     matches, length = MH[end_ref + 1][end_query + 1]
     assert H[end_ref + 1][end_query + 1] == best

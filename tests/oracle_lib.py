@@ -53,14 +53,15 @@ class _Stats(C.Structure):
     _fields_ = [("score", C.c_int32), ("end_query", C.c_int32), ("end_ref", C.c_int32), ("matches", C.c_int32), ("length", C.c_int32)]
 
 
-def sg_stats(s1, s2, open_, extend, table):
-    """(score, end_query, end_ref, matches, length) of the oracle DP with statistics (qo_sg_stats)."""
+def sg_stats(s1, s2, open_, extend, table, rule=native.STATS_PARASAIL6):
+    """(score, end_query, end_ref, matches, length) of the oracle DP with statistics (qo_sg_stats_rule; `rule` is one of
+    native.STATS_*, include/qcat_hip.h QCAT_STATS_*)."""
     t = np.ascontiguousarray(table, dtype=np.int8)
     st = _Stats()
     b1, b2 = s1.encode("latin-1", "replace"), s2.encode("latin-1", "replace")
-    fn = lib().qo_sg_stats
-    fn.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(_Stats)]
-    _check(fn(b1, len(b1), b2, len(b2), open_, extend, t.ctypes.data, C.byref(st)))
+    fn = lib().qo_sg_stats_rule
+    fn.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(_Stats)]
+    _check(fn(b1, len(b1), b2, len(b2), open_, extend, t.ctypes.data, int(rule), C.byref(st)))
     return st.score, st.end_query, st.end_ref, st.matches, st.length
 
 

@@ -144,6 +144,39 @@ def test_bench_under_a_launcher_environment_with_one_rank():
     assert_no_fraction_above_one(line)
 
 
+def test_rehearsal_of_eight_ranks_on_one_device():
+    """`bench.py --gpus 8` end to end on a ONE-GPU box (tests/rehearse_gpus8.py): the product's launcher starts 8 ranks
+    (NUMA / CPU-quota plan, QCAT_HOST_THREADS), every rank runs the unmodified bench.main() on device 0 with the
+    communicator stubbed over TCP (RCCL refuses several ranks per device): distinct seeds per rank, 1 M reads per shard,
+    the count vector summed over the ranks, barrier + max-over-ranks timing, host_inclusive at usable CPUs / 8 host
+    threads per rank, cpu_baseline + parity on rank 0, ONE JSON line with n_gpus = 8.  The value is that of eight
+    processes sharing one GPU -- the rehearsal proves the code path, not a scaling figure."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rehearse_gpus8.py"), "--launch", "--gpus", "8",
+                        "--reads", "1000000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                   # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["counts_total"] == 8000000 and line["scaling"] == "weak"
+    assert "config4" in line["config"]["workload"] and line["config"]["reads_total"] == 8000000
+    assert line["config"]["parallelism"] == "reads sharded x8"
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] <= 1
+    assert line["cpu_baseline"]["value"] > 0 and line["parity"]["mismatches_vs_oracle"] == 0
+    hi = line["host_inclusive"]
+    assert hi["value"] > 0 and hi["reads_per_gpu"] == 1000000
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+    assert hi["host_threads_per_rank"] == max(1, bench.usable_cores() // 8)
+    assert_no_fraction_above_one(line)
+    print("rehearsal: %.1f s, value %.1f M reads/s (8 ranks on ONE GPU), host_inclusive %.1f M reads/s at %d host threads per rank"
+          % (time.time() - t0, line["value"] / 1e6, hi["value"] / 1e6, hi["host_threads_per_rank"]))
+
+
 def assert_no_fraction_above_one(obj, path="line"):
     """every `frac` / `*_util*` field of the JSON line is a fraction of a hardware limit: never above 1"""
     if isinstance(obj, dict):

@@ -154,17 +154,21 @@ def test_simple_mode(i):
 
 
 def test_dp_statistics_against_the_independent_dp():
-    """qo_sg_stats (matches / alignment length along one optimal path, oracle/qcat_oracle.c) against the independent
-    scalar DP's sg_stats on seeded pairs: same score / end position as qo_sg, same tie order for the two statistics
-    (parity with parasail's own choice of path is unpinned -- nothing on a scanner path consumes them)."""
+    """qo_sg_stats_rule (matches / alignment length along one optimal path, oracle/qcat_oracle.c) against the independent
+    scalar DP's sg_stats on seeded pairs, under every rule of the shared switch (QCAT_STATS_*): parasail's recalled order
+    with matches over mapped codes (six- and five-letter alphabets) and round 3's order; same score / end position as
+    qo_sg under all of them.  Parity with parasail's own choice of path is unpinned -- nothing on a scanner path consumes
+    the two numbers."""
     import random
     import sys
     sys.path.insert(0, os.path.join(helpers.GOLDEN))
     import sg_independent as si
-    from qcat_amd import config as qconfig
+    from qcat_amd import config as qconfig, native
     cfg = qconfig.qcatConfig()
     rng = random.Random(20260929)
-    for matrix in (cfg.matrix, cfg.matrix_barcode):
+    differ = 0
+    for matrix, alphabet, rules in ((cfg.matrix, "ATGCNX", (native.STATS_PARASAIL6, native.STATS_ROUND3)),
+                                    (cfg.matrix_barcode, "ATGCN", (native.STATS_PARASAIL5, native.STATS_ROUND3))):
         tab = matrix.table
         alpha = "ATGCNX"
 
@@ -173,11 +177,35 @@ def test_dp_statistics_against_the_independent_dp():
             return int(tab[ib if ib >= 0 else 6][ia if ia >= 0 else 6])
         for _ in range(150):
             L, M = rng.randrange(1, 90), rng.randrange(1, 50)
-            s1 = "".join(rng.choice("ACGT" if rng.random() < 0.9 else "ACGTNRacgt") for _ in range(L))
-            s2 = "".join(rng.choice("ACGTN") for _ in range(M))
+            s1 = "".join(rng.choice("ACGT" if rng.random() < 0.9 else "ACGTNRYXacgtx") for _ in range(L))
+            s2 = "".join(rng.choice("ACGTN" if rng.random() < 0.95 else "RYX") for _ in range(M))
             if rng.random() < 0.5 and L > M:
                 p = rng.randrange(0, L - M + 1)
                 s1 = s1[:p] + "".join(c if (c != "N" and rng.random() > 0.1) else rng.choice("ACGT") for c in s2) + s1[p + M:]
             go, ge = rng.choice([(2, 2), (1, 1), (3, 1), (5, 2)])
-            assert tuple(si.sg_stats(s1, s2, go, ge, score)) == oracle_lib.sg_stats(s1, s2, go, ge, tab), (s1, s2, go, ge)
-            assert oracle_lib.sg_stats(s1, s2, go, ge, tab)[:3] == oracle_lib.sg(s1, s2, go, ge, tab)
+            got = {}
+            for rule in rules:
+                name = "round3" if rule == native.STATS_ROUND3 else "parasail"
+                got[rule] = oracle_lib.sg_stats(s1, s2, go, ge, tab, rule=rule)
+                assert tuple(si.sg_stats(s1, s2, go, ge, score, alphabet=alphabet, rule=name)) == got[rule], (s1, s2, go, ge, rule)
+                assert got[rule][:3] == oracle_lib.sg(s1, s2, go, ge, tab)
+            differ += got[rules[0]] != got[rules[1]]
+    assert differ > 0          # the rules are not the same function: some pair walks another path or counts '*' matches
+
+
+def test_mapped_code_matches_known_cases():
+    """What "a match = equal mapped codes" means, on hand-made pairs: two different letters outside the alphabet both map
+    to '*' and count under the parasail rules, not under round 3's; X is a letter of the adapter alphabet and '*' under
+    the barcode alphabet."""
+    from qcat_amd import config as qconfig, native
+    cfg = qconfig.qcatConfig()
+    tab = cfg.matrix.table
+    # ACGT R ACGT against ACGT Y ACGT: every letter on the diagonal (R/Y score 0, a gap would cost)
+    a6 = oracle_lib.sg_stats("ACGTRACGT", "ACGTYACGT", 2, 2, tab, rule=native.STATS_PARASAIL6)
+    r3 = oracle_lib.sg_stats("ACGTRACGT", "ACGTYACGT", 2, 2, tab, rule=native.STATS_ROUND3)
+    assert a6[:3] == r3[:3] and a6[4] == r3[4] == 9 and a6[3] == 9 and r3[3] == 8
+    # X against R: different codes over ATGCNX, both '*' over ATGCN
+    bt = cfg.matrix_barcode.table
+    x6 = oracle_lib.sg_stats("ACGTXACGT", "ACGTRACGT", 1, 1, bt, rule=native.STATS_PARASAIL6)
+    x5 = oracle_lib.sg_stats("ACGTXACGT", "ACGTRACGT", 1, 1, bt, rule=native.STATS_PARASAIL5)
+    assert x6[:3] == x5[:3] and x6[3] == 8 and x5[3] == 9

@@ -182,6 +182,40 @@ def test_two_jobs_of_one_world_size_do_not_cross_connect(tmp_path):
     assert struct.calcsize("<ii") == 8 and socket is not None
 
 
+def test_a_rank_whose_read_of_the_id_failed_is_served_again(tmp_path):
+    """A client that drops the connection before it has read (and acknowledged) the id asks again: rank 0 serves it a
+    second time and counts the rank once -- it used to skip a rank it had already answered, and the rank hung until the
+    deadline."""
+    import socket
+    import struct
+    import threading
+    import time
+    base = parallel.free_port()
+    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(base), "QCAT_RDZV_NONCE": "job-retry"}
+    got = {}
+
+    def run(rank, payload):
+        try:
+            got[rank] = parallel.exchange_id(rank, 3, lambda: payload, environ=env, timeout=60.0)
+        except Exception as exc:                      # noqa: BLE001
+            got[rank] = exc
+    srv = threading.Thread(target=run, args=(0, b"Z" * 128))
+    srv.start()
+    time.sleep(0.3)
+    # rank 1's first attempt: sends a valid request, then closes without reading the reply
+    nonce = parallel.job_nonce(env)
+    with socket.create_connection(("127.0.0.1", parallel._candidate_ports(env)[0]), timeout=5.0) as conn:
+        conn.sendall(parallel._MAGIC_REQ + nonce + struct.pack("<ii", 3, 1))
+    t0 = time.time()
+    ts = [threading.Thread(target=run, args=(r, None)) for r in (1, 2)]
+    for t in ts:
+        t.start()
+    for t in ts + [srv]:
+        t.join(timeout=90)
+    assert got[0] == got[1] == got[2] == b"Z" * 128
+    assert time.time() - t0 < 30.0
+
+
 def test_rank_cpu_plan_splits_nodes_and_quota():
     """launch(): rank r sits on the CPUs of its GPU's NUMA node, ranks sharing a node split it, and the host threads
     per rank are the container's usable CPUs / ranks (16-core quota, 8 ranks -> 2 threads each, no oversubscription)."""

@@ -20,7 +20,7 @@ def _pairs(seed, n):
     qs, ts = [], []
     for _ in range(n):
         L, M = rng.randrange(1, 400), rng.randrange(1, 110)
-        s1 = "".join(rng.choice("ACGT" if rng.random() < 0.93 else "ACGTNRacgtn") for _ in range(L))
+        s1 = "".join(rng.choice("ACGT" if rng.random() < 0.93 else "ACGTNRYXacgtnx") for _ in range(L))
         s2 = "".join(rng.choice("ACGTN") for _ in range(M))
         if rng.random() < 0.6 and L > M:                       # the target (with errors) somewhere inside the query
             p = rng.randrange(0, L - M + 1)
@@ -33,7 +33,7 @@ def _pairs(seed, n):
 
 
 @pytest.mark.parametrize("gaps", [(2, 2), (1, 1), (5, 2), (3, 1)])
-@pytest.mark.parametrize("stats", [False, True])
+@pytest.mark.parametrize("stats", [False, True, native.STATS_PARASAIL5, native.STATS_ROUND3])
 def test_device_alignments_equal_the_oracle(gaps, stats):
     cfg = config.qcatConfig()
     ctx = native.NativeContext(0)
@@ -41,7 +41,8 @@ def test_device_alignments_equal_the_oracle(gaps, stats):
     for matrix in (cfg.matrix, cfg.matrix_barcode):
         got = native.sg_align(ctx, qs, ts, gaps[0], gaps[1], matrix.table, with_stats=stats)
         for i, (q, t) in enumerate(zip(qs, ts)):
-            want = oracle_lib.sg_stats(q, t, gaps[0], gaps[1], matrix.table)
+            want = oracle_lib.sg_stats(q, t, gaps[0], gaps[1], matrix.table,
+                                       rule=native.STATS_PARASAIL6 if stats in (False, True) else stats)
             have = tuple(int(got[i][k]) for k in ("score", "end_query", "end_ref", "matches", "length"))
             assert have[:3] == want[:3], (i, q, t, have, want)
             assert have[3:] == (want[3:] if stats else (0, 0)), (i, q, t, have, want)

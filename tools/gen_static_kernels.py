@@ -241,14 +241,14 @@ def render():
                 s1, s0 = bs_shared_words(targets[0], rev, pre, CODE)
                 bh.write("    static constexpr int C = %d, KERNEL = %d, PRE = %d;\n    static constexpr unsigned S1 = 0x%Xu, S0 = 0x%Xu;      // letters of the shared columns\n"
                          % (own, kid, pre, s1, s0))
-                bh.write("    static __device__ __forceinline__ void rows(int kase, const uint4* __restrict__ s_rows, int L, int lane, bool shared, "
+                bh.write("    static __device__ __forceinline__ void rows(int kase, const BsRowArgs& ra, "
                          "u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n")
                 for pr, (ta, tb, up_) in enumerate(pairs):
                     for half, t in ((0, ta), (1, tb)):
                         if half == 1 and tb == ta:
                             continue
                         w1, w0 = bs_words(t, rev, pre, CODE)
-                        bh.write("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(s_rows, L, lane, shared, h1, h0, f); break;\n"
+                        bh.write("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(ra, h1, h0, f); break;\n"
                                  % (2 * pr + half, w1, w0))
                 bh.write("        default: break;\n        }\n    }\n};\n")
                 bs_structs.append((kid, len(targets), "".join(bh.parts)))
