@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QCAT_ABI_VERSION 3
+#define QCAT_ABI_VERSION 4
 
 /* Base code space shared by host and device (qcat_amd/codes.py): parasail's mapper sends the
  * alphabet letters (either case) to their index and everything else to the '*' row
@@ -71,7 +71,12 @@ enum { QCAT_ENDS_5P = 1,          /* scan() on the 5' window only (BASELINE conf
 
 /* One barcode set of one template (qcat/layout.py:176-189 get_barcode_set).
  * `sequences` holds n * barcode_len ASCII characters (NUL-terminated: a shorter string is rejected with
- * QCAT_ERR_ARG), barcode b at sequences + b*barcode_len -- every barcode of a set has the same length.
+ * QCAT_ERR_ARG), barcode b at sequences + b*barcode_len.
+ * `lengths` (optional, ABI 4): barcode b has lengths[b] letters, 1 <= lengths[b] <= barcode_len, the rest of its row is
+ * padding (any non-NUL character).  The reference aligns every barcode with its own length and normalises by it
+ * (qcat/scanner_base.py:108-119); only a user FASTA in simple mode (scanner_simple.py:24-29) can hold barcodes of unequal
+ * length -- a template's placeholder has ONE length (layout.py:55-61) -- so unequal lengths are accepted in
+ * QCAT_MODE_SIMPLE and answered with QCAT_ERR_UNSUPPORTED elsewhere.  NULL: every barcode has barcode_len letters.
  * `ids[b]` is a dense integer standing for Barcode.id -- only equality is ever used
  * (qcat/scanner_base.py:589); the host maps YAML ids to ints. */
 typedef struct qcat_barcode_set_desc {
@@ -79,6 +84,7 @@ typedef struct qcat_barcode_set_desc {
     const int32_t* ids;
     int32_t        n;
     int32_t        barcode_len;
+    const int32_t* lengths;
 } qcat_barcode_set_desc;
 
 /* One adapter template = one AdapterLayout (qcat/layout.py:15-70).  Placeholder geometry is
@@ -200,6 +206,8 @@ typedef struct qcat_kit_info {
     int32_t n_groups, n_static_groups;
     int32_t bitslice_groups;    /* low 16 bits: groups the bit-sliced barcode kernels take (big batches);
                                    high 16 bits: those of them with the target letters compiled in */
+    int32_t bitslice_templates; /* (ABI 4) templates with a bit-sliced ADAPTER plan: low 8 bits two stages, bits 8-15 four
+                                   stages (medium batches), bits 16-23 four wide stages (templates too long for two) */
 } qcat_kit_info;
 int  qcat_kit_describe(const qcat_kit* kit, qcat_kit_info* out);
 
@@ -261,6 +269,15 @@ int  qcat_scan_batch_auto(qcat_ctx* ctx, const qcat_kit* kit,
                           const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                           qcat_result* out, int64_t* counts, int32_t* chosen_kit_slot,
                           int64_t* votes, int64_t* first_read);
+
+/* The same with the reads as ONE POINTER AND ONE LENGTH PER READ instead of the concatenated form: what a host language that
+ * holds a string object per read has at hand -- the Python drop-in passes the buffers of the caller's str objects
+ * (qcat/scanner_base.py:714-733 takes `read_sequences`, a list of str), so a batch is not joined and encoded first
+ * (0.8 ms of a 3.3 ms call on 4000 reads).  The buffers must stay valid and unchanged during the call. */
+int  qcat_scan_batch_auto_ptrs(qcat_ctx* ctx, const qcat_kit* kit,
+                               const uint8_t* const* reads, const uint64_t* lengths, uint32_t n_reads,
+                               qcat_result* out, int64_t* counts, int32_t* chosen_kit_slot,
+                               int64_t* votes, int64_t* first_read);
 
 /* replaces: BarcodeScanner.scan(read_sequence, ...) on sequences of ANY length (qcat/scanner_base.py:466-477;
  * scanner_epi2me.py:33-144, scanner_dual.py:35-146) -- the form scan_middle uses on read interiors

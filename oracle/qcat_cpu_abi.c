@@ -53,7 +53,7 @@ int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {
         const qcat_template_desc* s = &desc->templates[t];
         need += (size_t)(s->length > 0 ? s->length : 0) + 8;
         for (int i = 0; i < 2; ++i)
-            if (s->sets[i].n > 0) need += (size_t)s->sets[i].n * (size_t)s->sets[i].barcode_len + (size_t)s->sets[i].n * 4 + 16;
+            if (s->sets[i].n > 0) need += (size_t)s->sets[i].n * (size_t)s->sets[i].barcode_len + (size_t)s->sets[i].n * 8 + 24;
     }
     qcat_kit* k = (qcat_kit*)calloc(1, sizeof *k);
     k->blob = (char*)calloc(1, need + 16);
@@ -73,6 +73,10 @@ int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {
             p = (char*)(((uintptr_t)p + 7) & ~(uintptr_t)7);
             memcpy(p, s->sets[i].ids, (size_t)s->sets[i].n * 4);
             k->tpl[t].sets[i].ids = (const int32_t*)p; p += (size_t)s->sets[i].n * 4;
+            if (s->sets[i].lengths) {                                /* (ABI 4: per-barcode lengths travel with the kit) */
+                memcpy(p, s->sets[i].lengths, (size_t)s->sets[i].n * 4);
+                k->tpl[t].sets[i].lengths = (const int32_t*)p; p += (size_t)s->sets[i].n * 4;
+            }
         }
     }
     /* validate by one empty scan: the oracle checks the descriptor when it prepares the kit */

@@ -208,6 +208,7 @@ typedef struct qo_set {
     int n, blen, tlen, uplen, downlen;
     uint8_t* targets;          /* n * tlen codes: up + barcode + down */
     const int32_t* ids;
+    const int32_t* lens;       /* simple mode, a user FASTA: barcode b has lens[b] <= blen letters (NULL: all blen) */
 } qo_set;
 
 typedef struct qo_tpl {
@@ -267,8 +268,23 @@ int qo_kit_prepare(const qcat_kit_desc* d, qo_kit** out) {
         for (int i = 0; i < 2; ++i) {
             const qcat_barcode_set_desc* bs = &s->sets[i];
             qo_set* q = &p->sets[i];
-            q->n = bs->n; q->blen = bs->barcode_len; q->ids = bs->ids;
+            q->n = bs->n; q->blen = bs->barcode_len; q->ids = bs->ids; q->lens = NULL;
             if (bs->n <= 0) { q->n = 0; continue; }
+            if (bs->lengths) {                                   /* ABI 4: barcodes of unequal length, simple mode only */
+                int ragged = 0;
+                for (int b = 0; b < bs->n; ++b) {
+                    if (bs->lengths[b] < 1 || bs->lengths[b] > bs->barcode_len) {
+                        snprintf(qo_err, sizeof qo_err, "template %d set %d: lengths[%d] outside 1..barcode_len", t, i, b);
+                        qo_kit_free(k); return QCAT_ERR_ARG;
+                    }
+                    ragged = ragged || bs->lengths[b] != bs->barcode_len;
+                }
+                if (ragged && d->mode != QCAT_MODE_SIMPLE) {
+                    snprintf(qo_err, sizeof qo_err, "barcodes of unequal length are covered in simple mode only");
+                    qo_kit_free(k); return QCAT_ERR_UNSUPPORTED;
+                }
+                if (ragged) q->lens = bs->lengths;
+            }
             /* contexts: layout.py:191-238 */
             int n = d->barcode_context_length, up0 = 0, up1 = 0, dn0 = 0, dn1 = 0;
             if (p->bc_end[i] > -1) {
@@ -444,19 +460,23 @@ static qo_scan qo_scan_end(const qo_kit* k, const uint8_t* w, int L, qcat_end_tr
  * find_highest_scoring_barcode.  adapter is None, adapter_end = end_query of the winner's alignment. */
 static qo_scan qo_scan_simple(const qo_kit* k, const uint8_t* w, int L, qcat_end_trace* tr, int16_t* rows) {
     const qo_set* s = &k->tpl[0].sets[0];
-    int best = -1, best_raw = 0, best_end = -1;
+    int best = -1, best_raw = 0, best_end = -1, best_len = 1;
+    double best_score = 0.0;
     if (L > 0) {
         for (int b = 0; b < s->n; ++b) {
             qo_align a;
-            qo_sg_codes(w, L, s->targets + (size_t)b * s->tlen, s->tlen, 1, 1, k->d.barcode_matrix, &a);
+            const int tl = s->lens ? s->lens[b] : s->tlen;       /* every barcode with its own length (:112-117) */
+            qo_sg_codes(w, L, s->targets + (size_t)b * s->tlen, tl, 1, 1, k->d.barcode_matrix, &a);
             if (rows) rows[b] = (int16_t)a.score;
-            if (best < 0 || best_raw == 0 || best_raw < a.score) { best = b; best_raw = a.score; best_end = a.end_query; }
+            const double sc = a.score * 100.0 / (1.0 * tl);      /* scanner_base.py:119 */
+            /* `if not max_score or max_score < score` (:125) */
+            if (best < 0 || best_score == 0.0 || best_score < sc) { best = b; best_raw = a.score; best_end = a.end_query; best_len = tl; best_score = sc; }
         }
     }
     qo_scan r = qo_empty();
-    double score = best >= 0 ? best_raw * 100.0 / (1.0 * s->tlen) : 0.0;
+    double score = best >= 0 ? best_raw * 100.0 / (1.0 * best_len) : 0.0;
     if (!(score < k->d.min_quality)) {                       /* `if identity < self.min_quality: return empty` */
-        r.has_barcode = best >= 0; r.bc[0] = best; r.raw = best >= 0 ? best_raw : 0; r.den = best >= 0 ? s->tlen : 1;
+        r.has_barcode = best >= 0; r.bc[0] = best; r.raw = best >= 0 ? best_raw : 0; r.den = best >= 0 ? best_len : 1;
         r.score = score; r.adapter = -1; r.adapter_end = best_end; r.exit_status = 0;
     }
     if (tr) {

@@ -32,7 +32,8 @@ extern "C" void qcat_abs_launch_pack_planes(unsigned n_tiles, void* stream, cons
 }
 
 // kind 0: fused two-template plan `id` (g_static_fused), kind 1: single-template plan `id` (g_static_templates); kind 2: the
-// single-template plan of four stages (k_adapter_ms, four waves per tile: medium batches).  Returns 0 when the plan does not
+// single-template plan of four stages (k_adapter_ms, four waves per tile: medium batches); kind 3: the four-stage plan of a
+// template too long for two stages (k_adapter_mw, up to 26 columns per stage).  Returns 0 when the plan does not
 // exist (the caller keeps the other form or the binary16 kernel); args null: only asks
 extern "C" int qcat_abs_launch(int kind, int id, unsigned grid, void* stream, const void* args) {
     const qk::AbsArgs& a = *static_cast<const qk::AbsArgs*>(args);
@@ -41,6 +42,14 @@ extern "C" int qcat_abs_launch(int kind, int id, unsigned grid, void* stream, co
         switch (id) {
 #define QCAT_ABS_CASE(N) case N: if (args) hipLaunchKernelGGL(qk::k_adapter_ms<qabs::QAM_T##N>, dim3(grid), dim3(256), 0, s, a); return 1;
             QCAT_ABS_FOR_EACH_TEMPLATE_MS(QCAT_ABS_CASE)
+#undef QCAT_ABS_CASE
+        default: return 0;
+        }
+    }
+    if (kind == 3) {
+        switch (id) {
+#define QCAT_ABS_CASE(N) case N: if (args) hipLaunchKernelGGL(qk::k_adapter_mw<qabs::QAW_T##N>, dim3(grid), dim3(256), 0, s, a); return 1;
+            QCAT_ABS_FOR_EACH_TEMPLATE_MW(QCAT_ABS_CASE)
 #undef QCAT_ABS_CASE
         default: return 0;
         }

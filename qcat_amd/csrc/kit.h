@@ -62,6 +62,8 @@ struct DevSet {
     int32_t bs_rev;             // ... rows and target letters run backwards (the downstream context is the longer one)
     int32_t bs_kernel;          // bit-sliced kernel with this set's letters compiled in (static_generated.inc / run-time code), -1: none
     int32_t bs_case_off;        // ids blob: per barcode its case of that kernel
+    int32_t len_off;            // simple mode, barcodes of unequal length: ids blob, per barcode (length, min_raw_pass, min_raw_conflict);
+                                // -1: every barcode has blen letters (the set's own tlen / thresholds apply)
 };
 
 constexpr int BS_C_MIN = 20, BS_C_MAX = 48;    // own columns (tlen - bs_pre) the bit-sliced kernels are instantiated for
@@ -82,6 +84,8 @@ struct DevTpl {
     int32_t static_kernel;      // generated static-letter adapter kernel (kernels_static.inc), -1: none
     int32_t fused_kernel;       // generated kernel that scans this template AND `fused_partner` in one pass, -1: none
     int32_t fused_partner;
+    int32_t abs_jit;            // bit-sliced adapter plans in the kit's run-time generated code (qcat_kit_attach_code, template flag bits 1..3):
+                                // 1 two stages (qj_abs_<t>), 2 four stages of <= 13 columns (qj_absm_<t>), 4 four wide stages (qj_absw_<t>)
     DevSet sets[2];
 };
 

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -111,6 +112,7 @@ struct KitOnDevice {
     // static-letter kernels compiled for this kit at run time (qcat_kit_attach_code)
     hipModule_t jit_module = nullptr;
     hipFunction_t jit_ad[MAX_T] = {}, jit_am[MAX_T] = {}, jit_bc[MAX_T * 2] = {}, jit_bs[MAX_T * 2] = {};
+    hipFunction_t jit_abs[3][MAX_T] = {};          // bit-sliced adapter plans: qj_abs_<t>, qj_absm_<t>, qj_absw_<t>
 };
 
 struct qcat_kit {
@@ -129,10 +131,11 @@ namespace qk {
 static inline void jit_launch(int kind, int index, dim3 grid, hipStream_t stream, const void* args) {
     hipFunction_t f = nullptr;
     if (g_jit) f = kind == QCAT_JIT_ADAPTER ? g_jit->jit_ad[index] : (kind == QCAT_JIT_MIDDLE ? g_jit->jit_am[index] :
-                   (kind == QCAT_JIT_BITSLICE ? g_jit->jit_bs[index] : g_jit->jit_bc[index]));
+                   (kind == QCAT_JIT_BITSLICE ? g_jit->jit_bs[index] :
+                    (kind >= QCAT_JIT_ABS2 && kind <= QCAT_JIT_ABSW ? g_jit->jit_abs[kind - QCAT_JIT_ABS2][index] : g_jit->jit_bc[index])));
     if (!f) { g_packed_err = "run-time generated kernel missing from the kit's code object"; g_jit_rc = QCAT_ERR_DEVICE; return; }
     void* params[1] = {const_cast<void*>(args)};
-    const unsigned threads = kind == QCAT_JIT_BITSLICE ? BS_WAVES * 64 : PK_WAVES * 64;
+    const unsigned threads = kind == QCAT_JIT_BITSLICE ? BS_WAVES * 64 : (kind == QCAT_JIT_ABS2 ? 128u : (kind == QCAT_JIT_ABSM || kind == QCAT_JIT_ABSW ? 256u : PK_WAVES * 64));
     const hipError_t e = hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, threads, 1, 1, 0, stream, params, nullptr);
     if (e != hipSuccess) { g_packed_err = std::string("launch of a run-time generated kernel: ") + hipGetErrorString(e); g_jit_rc = QCAT_ERR_DEVICE; }
 }
@@ -215,7 +218,12 @@ extern "C" int qcat_kit_attach_code_quads(qcat_kit* k, const void* code, uint64_
         }
     k->jit_code.assign((const uint8_t*)code, (const uint8_t*)code + size);
     for (int t = 0; t < d.nt; ++t) {
-        if (template_flags[t] && d.adapter_f16 && d.tpl[t].static_kernel < 0) { d.tpl[t].static_kernel = QCAT_JIT_BASE + t; k->jit_tpl[t] = true; }
+        if ((template_flags[t] & 1) && d.adapter_f16 && d.tpl[t].static_kernel < 0) {
+            d.tpl[t].static_kernel = QCAT_JIT_BASE + t; k->jit_tpl[t] = true;
+            // bits 1..3 of a template flag: the code object also holds bit-sliced adapter plans of this template (qj_abs_<t>
+            // two stages, qj_absm_<t> four stages, qj_absw_<t> four wide stages); only kits the path takes at all use them
+            if (d.abs_ok) d.tpl[t].abs_jit = (template_flags[t] >> 1) & 7;
+        }
         for (int s = 0; s < nsets; ++s) {
             DevSet& q = d.tpl[t].sets[s];
             if (!group_flags[t * 2 + s] || !d.barcode_f16 || q.static_kernel >= 0 || q.n <= 0) continue;
@@ -259,6 +267,10 @@ extern "C" int qcat_kit_describe(const qcat_kit* k, qcat_kit_info* out) {
     const int nsets = d.mode == QCAT_MODE_DUAL ? 2 : 1;
     for (int t = 0; t < d.nt; ++t) {
         if (d.tpl[t].static_kernel >= 0) out->n_static_templates++;
+        if (d.abs_ok) {
+            const int forms = abs_forms(d, t);
+            out->bitslice_templates += (forms & 1 ? 1 : 0) + (forms & 2 ? 0x100 : 0) + (forms & 4 ? 0x10000 : 0);
+        }
         for (int s = 0; s < nsets; ++s) {
             out->n_groups++;
             if (d.tpl[t].sets[s].static_kernel >= 0) out->n_static_groups++;
@@ -313,6 +325,11 @@ static int kit_upload(qcat_kit* k, KitOnDevice& kd) {
                 HIPCHK(hipModuleGetFunction(&kd.jit_ad[t], kd.jit_module, name));
                 snprintf(name, sizeof name, "qj_am_%d", t);
                 HIPCHK(hipModuleGetFunction(&kd.jit_am[t], kd.jit_module, name));
+                static const char* const abs_names[3] = {"qj_abs_%d", "qj_absm_%d", "qj_absw_%d"};
+                for (int f = 0; f < 3; ++f) if (h.dk.tpl[t].abs_jit & (1 << f)) {
+                    snprintf(name, sizeof name, abs_names[f], t);
+                    HIPCHK(hipModuleGetFunction(&kd.jit_abs[f][t], kd.jit_module, name));
+                }
             }
             for (int s2 = 0; s2 < 2; ++s2) if (k->jit_grp[t * 2 + s2]) {
                 snprintf(name, sizeof name, "qj_bc_%d", t * 2 + s2);
@@ -596,18 +613,30 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         c->ring_marks[c->ring_used] = 0;
         c->ev = c->evr[c->ring_used++];
     }
-    if (!keep_counts) HIPCHK(hipMemsetAsync(c->counts, 0, (size_t)hk.n_buckets * 8, c->stream));
-    if (n == 0) return 0;
+    // the fills of a scan leave as ONE launch in front of the pack kernel (k_fill_multi): count vector, letter flags, and --
+    // with the job tables and the adapter tile flags sized here instead of after the pack kernel -- theirs too
+    const bool use_packed = hk.fast_ok && !c->force_generic && packed_supported(hk);
+    g_fill_defer = n != 0 && getenv("QCAT_HIP_NO_FILL_MERGE") == nullptr;
+    if (!keep_counts) HIPCHK(packed_fill(c->counts, 0, (size_t)hk.n_buckets * 8, c->stream));
+    if (n == 0) { HIPCHK(packed_fill_flush(c->stream)); return 0; }
     if (c->timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));   // (an empty batch returned above: its slot holds no marks)
 
     KitPtrs kp{kd->kit, kd->codes, kd->ids, kd->tables};
     g_jit = kd;
-    const bool use_packed = hk.fast_ok && !c->force_generic && packed_supported(hk);
+    c->packed.prepared = false; c->packed.abs_zeroed = 0; c->packed.redo_zeroed = false;
     if (resume_kit_mask < 0) {
         uint64_t threads = (uint64_t)n_ends * (WIN_STRIDE / 16);
         uint32_t blocks = (uint32_t)((threads + 255) / 256);
-        HIPCHK(hipMemsetAsync(c->wspec, 0, n_ends, c->stream));
+        HIPCHK(packed_fill(c->wspec, 0, n_ends, c->stream));
         c->packed.abs_ready = 0;
+        if (g_fill_defer && use_packed && hk.mode != QCAT_MODE_SIMPLE) {
+            c->packed.slim = use_packed && !debug && getenv("QCAT_HIP_NO_SLIM") == nullptr;     // (packed_prepare sizes the slim buffers)
+            if ((rc = packed_prepare(c->stream, hk, (uint32_t)n_ends, &c->packed))) { g_fill_defer = false; g_fill.n = 0; return set_err(rc, packed_last_error()); }
+            c->packed.prepared = true;
+            if (getenv("QCAT_HIP_PACK_PLANES") == nullptr && packed_abs_wanted(hk, (uint32_t)n_ends, true) &&
+                (rc = packed_abs_buffers(c->stream, hk, (uint32_t)n_ends, &c->packed))) { g_fill_defer = false; g_fill.n = 0; return set_err(rc, packed_last_error()); }
+        }
+        HIPCHK(packed_fill_flush(c->stream));
         if (use_packed && hk.mode != QCAT_MODE_SIMPLE && getenv("QCAT_HIP_PACK_PLANES") != nullptr && packed_abs_wanted(hk, (uint32_t)n_ends, true)) {
             // (A/B switch, off by default) the windows and their letter planes in one pass (kernels_abs.inc: k_pack_planes).
             // Measured and dropped: 5.1 ms against 1.67 + 0.85 ms for k_pack_windows + k_abs_planes on config 3 -- a wave that
@@ -628,6 +657,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         }
         mark(c, "k_pack_windows");
     }
+    HIPCHK(packed_fill_flush(c->stream));               // (a resumed scan: the count vector's fill)
     if (hk.mode == QCAT_MODE_SIMPLE && adapter_only) return set_err(QCAT_ERR_ARG, "simple mode has no adapter templates to vote with");
     if (resume_kit_mask >= 0 && !(use_packed && c->packed.slices_single))
         return set_err(QCAT_ERR_UNSUPPORTED, "the adapter pass of this kit cannot be resumed per kit (table or general kernels)");
@@ -782,13 +812,26 @@ extern "C" int qcat_batch_upload(qcat_ctx* c, const uint8_t* bases, const uint64
 // all they send over PCIe: every read is compacted to head + tail (reads up to 2n stay whole, which
 // keeps the two windows byte-identical), the real length travels in a separate array for the trims.
 // The compaction runs on a few host threads into pinned memory.  --detect-middle needs whole reads.
+// `ptrs` / `lens` (both or neither): the reads as one pointer and one length per read instead of the concatenated form
+// (qcat_scan_batch_ptrs: a host language that holds a string object per read passes the objects' own buffers)
 static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t* bases, const uint64_t* offsets,
-                                uint32_t n_reads, qcat_batch** out) {
+                                uint32_t n_reads, qcat_batch** out, const uint8_t* const* ptrs = nullptr, const uint64_t* lens = nullptr) {
     const DevKit& hk = kit->hk.dk;
+    std::vector<uint8_t> cat;
+    std::vector<uint64_t> cat_off;
+    if (ptrs && (hk.scan_middle || n_reads < 256 || getenv("QCAT_HIP_FULL_UPLOAD"))) {      // the paths that take whole reads: concatenate
+        cat_off.resize((size_t)n_reads + 1);
+        uint64_t tot = 0;
+        for (uint32_t r = 0; r < n_reads; ++r) { cat_off[r] = tot; tot += lens[r]; }
+        cat_off[n_reads] = tot;
+        cat.resize((size_t)tot + 1);
+        for (uint32_t r = 0; r < n_reads; ++r) if (lens[r]) memcpy(cat.data() + cat_off[r], ptrs[r], (size_t)lens[r]);
+        bases = cat.data(); offsets = cat_off.data(); ptrs = nullptr;
+    }
     if (hk.scan_middle || n_reads < 256 || getenv("QCAT_HIP_FULL_UPLOAD"))
         return qcat_batch_upload(c, bases, offsets, n_reads, out);
-    if (!c || !offsets || !out || (!bases && offsets[n_reads] > 0)) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
-    if (offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
+    if (!c || !out || (!ptrs && (!offsets || (!bases && offsets[n_reads] > 0)))) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
+    if (!ptrs && offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
     HIPCHK(hipSetDevice(c->device));
     const uint64_t n = (uint64_t)hk.max_align;
     const bool both = hk.ends == QCAT_ENDS_BOTH;
@@ -804,8 +847,9 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
     uint64_t total = 0;
     c->pin_offsets[0] = 0;
     for (uint32_t r = 0; r < n_reads; ++r) {
-        if (offsets[r + 1] < offsets[r]) return set_err(QCAT_ERR_ARG, "offsets must be non-decreasing");
-        const uint64_t len = offsets[r + 1] - offsets[r];
+        if (!ptrs && offsets[r + 1] < offsets[r]) return set_err(QCAT_ERR_ARG, "offsets must be non-decreasing");
+        const uint64_t len = ptrs ? lens[r] : offsets[r + 1] - offsets[r];
+        if (ptrs && len && !ptrs[r]) return set_err(QCAT_ERR_ARG, "null read pointer");
         if (len > 0xFFFFFFFFull) return set_err(QCAT_ERR_UNSUPPORTED, "read longer than 4 Gb");
         c->pin_len[r] = (uint32_t)len;
         total += len <= keep ? len : keep;
@@ -821,8 +865,8 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
         const unsigned nthreads = std::min<unsigned>(host_threads(), std::max<uint32_t>(1u, n_reads / 16384u));
         auto work = [&](uint32_t r0, uint32_t r1) {
             for (uint32_t r = r0; r < r1; ++r) {
-                const uint8_t* src = bases + offsets[r];
-                const uint64_t len = offsets[r + 1] - offsets[r];
+                const uint8_t* src = ptrs ? ptrs[r] : bases + offsets[r];
+                const uint64_t len = ptrs ? lens[r] : offsets[r + 1] - offsets[r];
                 uint8_t* dst = c->pin_bases + c->pin_offsets[r];
                 if (len <= keep) { memcpy(dst, src, len); continue; }
                 memcpy(dst, src, n);
@@ -864,7 +908,8 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
     if (total) HIPCHK(hipMemcpyAsync(b->bases, c->pin_bases, total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b->offsets, c->pin_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b->true_len, c->pin_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));           // the pinned staging is reused by the next call
+    // (no synchronisation here: every caller hands results back to the host and drains the stream for that before it returns,
+    //  so the pinned staging is free again when the next call fills it -- one round trip less per 4000-read batch)
     *out = guard.release();
     return 0;
 }
@@ -1292,48 +1337,74 @@ extern "C" int qcat_detect_kit(qcat_ctx* c, const qcat_kit* ckit, const uint8_t*
     return 0;
 }
 
-extern "C" int qcat_scan_batch_auto(qcat_ctx* c, const qcat_kit* ckit, const uint8_t* bases, const uint64_t* offsets,
-                                    uint32_t n_reads, qcat_result* out, int64_t* counts, int32_t* chosen_kit_slot,
-                                    int64_t* votes, int64_t* first_read) {
-    if (!c || !ckit || !offsets || !out || !chosen_kit_slot) return set_err(QCAT_ERR_ARG, "qcat_scan_batch_auto: null argument");
+// the kit-auto scan of one batch.  Round 4: ONE host synchronisation -- the vote is counted AND decided on the device
+// (k_vote, k_pick_kit), the second pass reads the voted kit slot there (k_adapter_finish), and votes, choice, records and
+// counts come back together.  (Round 3 waited for the upload, for the votes and for the records: three round trips in a call
+// whose kernels take 0.3 ms.)
+static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t* bases, const uint64_t* offsets,
+                                const uint8_t* const* ptrs, const uint64_t* lens,
+                                uint32_t n_reads, qcat_result* out, int64_t* counts, int32_t* chosen_kit_slot,
+                                int64_t* votes, int64_t* first_read) {
+    if (!c || !ckit || (n_reads && !offsets && !ptrs) || !out || !chosen_kit_slot) return set_err(QCAT_ERR_ARG, "qcat_scan_batch_auto: null argument");
     qcat_kit* kit = const_cast<qcat_kit*>(ckit);
     const DevKit& hk = kit->hk.dk;
     if (hk.ends != QCAT_ENDS_BOTH) return set_err(QCAT_ERR_ARG, "qcat_scan_batch_auto needs a kit created with QCAT_ENDS_BOTH");
     *chosen_kit_slot = -1;
+    if (!n_reads) return 0;                                     // (an empty batch: nobody votes, nothing to scan)
     qcat_batch* b = nullptr;
-    int rc = batch_upload_windows(c, kit, bases, offsets, n_reads, &b);
+    int rc = batch_upload_windows(c, kit, bases, offsets, n_reads, &b, ptrs, lens);
     if (rc) return rc;
+    BatchGuard guard(b);
+    // (a failed step drains the stream before it returns: the upload may still be reading the pinned staging)
+    auto drained = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
+    // pass 1: every template of every kit against both ends (qcat/scanner_base.py:662-678)
+    if ((rc = scan_resident_impl(c, kit, b, false, 0, true))) return drained(rc);
+    KitOnDevice* kd = nullptr;
+    if ((rc = kit_on_device(kit, c->device, &kd))) return drained(rc);
+    if (!c->vote_buf) HIPCHK(hipMalloc((void**)&c->vote_buf, 2 * MAX_T * 8 + 16));
+    unsigned long long* d = c->vote_buf;
+    int32_t* chosen_dev = reinterpret_cast<int32_t*>(d + 2 * MAX_T);
+    g_fill_defer = true;
+    HIPCHK(packed_fill(d, 0, MAX_T * 8, c->stream));
+    HIPCHK(packed_fill(d + MAX_T, 0xFF, MAX_T * 8, c->stream));
+    HIPCHK(packed_fill_flush(c->stream));
+    const uint32_t blocks = std::min<uint32_t>((n_reads + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_vote, dim3(blocks), dim3(256), 0, c->stream, kd->kit, c->recs, n_reads, d, d + MAX_T);
+    hipLaunchKernelGGL(k_pick_kit, dim3(1), dim3(1), 0, c->stream, kd->kit, d, d + MAX_T, chosen_dev);
+    // pass 2: detect_barcode per read with the voted kit's templates (:714-733): the adapter alignments of the vote are still
+    // on the device -- only their merge (the kit slot read from chosen_dev), the barcode phase and the finalisation run now
+    c->packed.kit_slot_dev = chosen_dev;
+    if ((rc = scan_resident_impl(c, kit, b, false, 0, false, RESUME_KIT_ON_DEVICE))) return drained(rc);
     unsigned long long hv[MAX_T], hf[MAX_T];
-    rc = vote_resident(c, kit, b, hv, hf);
-    if (!rc && n_reads) {
-        // detect_kit (qcat/scanner_base.py:662-678): votes folded onto kit names; most votes wins, equal counts
-        // keep the order of first appearance (dict insertion order + stable sort, :657-660)
-        unsigned long long cnt[MAX_T] = {}, first[MAX_T];
-        for (int s = 0; s < MAX_T; ++s) first[s] = ~0ull;
-        for (int t = 0; t < hk.nt; ++t) {
-            const int s = hk.tpl[t].kit_slot;
-            cnt[s] += hv[t];
-            if (hv[t] && hf[t] < first[s]) first[s] = hf[t];
-            if (votes) votes[t] += (int64_t)hv[t];
-            if (first_read) first_read[t] = hf[t] == ~0ull ? (int64_t)n_reads : (int64_t)hf[t];
-        }
-        int best = -1;
-        for (int s = 0; s < hk.n_kit_slots; ++s)
-            if (cnt[s] && (best < 0 || cnt[s] > cnt[best] || (cnt[s] == cnt[best] && first[s] < first[best]))) best = s;
-        *chosen_kit_slot = best;
-        // detect_barcode per read with the voted kit's templates (:714-733): the adapter alignments of the vote
-        // are still on the device -- only their merge, the barcode phase and the finalisation run now
-        if (best >= 0) rc = scan_resident_impl(c, kit, b, false, 0, false, best);
-        else rc = set_err(QCAT_ERR_DEVICE, "qcat_scan_batch_auto: no read voted");
-        if (!rc) rc = qcat_ctx_fetch_results(c, out, n_reads);
-        if (!rc && counts) {
-            std::vector<int64_t> tmp((size_t)hk.n_buckets);
-            rc = qcat_ctx_fetch_counts(c, tmp.data(), hk.n_buckets);
-            if (!rc) for (size_t i = 0; i < tmp.size(); ++i) counts[i] += tmp[i];
-        }
+    int32_t chosen = -1;
+    std::vector<int64_t> tmp(counts ? (size_t)hk.n_buckets : 0);
+    HIPCHK(hipMemcpyAsync(hv, d, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hf, d + MAX_T, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&chosen, chosen_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(out, c->results, (size_t)n_reads * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream));
+    if (counts) HIPCHK(hipMemcpyAsync(tmp.data(), c->counts, (size_t)hk.n_buckets * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int t = 0; t < hk.nt; ++t) {
+        if (votes) votes[t] += (int64_t)hv[t];
+        if (first_read) first_read[t] = hf[t] == ~0ull ? (int64_t)n_reads : (int64_t)hf[t];
     }
-    qcat_batch_destroy(b);
-    return rc;
+    *chosen_kit_slot = chosen;
+    if (chosen < 0) return set_err(QCAT_ERR_DEVICE, "qcat_scan_batch_auto: no read voted");
+    if (counts) for (size_t i = 0; i < tmp.size(); ++i) counts[i] += tmp[i];
+    return 0;
+}
+
+extern "C" int qcat_scan_batch_auto(qcat_ctx* c, const qcat_kit* ckit, const uint8_t* bases, const uint64_t* offsets,
+                                    uint32_t n_reads, qcat_result* out, int64_t* counts, int32_t* chosen_kit_slot,
+                                    int64_t* votes, int64_t* first_read) {
+    return scan_batch_auto_impl(c, ckit, bases, offsets, nullptr, nullptr, n_reads, out, counts, chosen_kit_slot, votes, first_read);
+}
+
+extern "C" int qcat_scan_batch_auto_ptrs(qcat_ctx* c, const qcat_kit* ckit, const uint8_t* const* reads, const uint64_t* lengths,
+                                         uint32_t n_reads, qcat_result* out, int64_t* counts, int32_t* chosen_kit_slot,
+                                         int64_t* votes, int64_t* first_read) {
+    if (n_reads && (!reads || !lengths)) return set_err(QCAT_ERR_ARG, "qcat_scan_batch_auto_ptrs: null argument");
+    return scan_batch_auto_impl(c, ckit, nullptr, nullptr, reads, lengths, n_reads, out, counts, chosen_kit_slot, votes, first_read);
 }
 
 extern "C" int qcat_scan_batch(qcat_ctx* c, const qcat_kit* kit,

@@ -28,6 +28,7 @@ import subprocess
 import tempfile
 import threading
 
+from . import abs_plan
 from .codes import ASCII_TO_CODE
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
@@ -144,6 +145,44 @@ def _pair_up(targets, flank):
     return sorted(pairs)
 
 
+def _abs_ok(descriptor):
+    """the rule of kit_prepare.inc (DevKit::abs_ok): the bit-sliced adapter kernels are built on match 5 / mismatch -2 /
+    anything against a template N -1 / gap open = extend = 2 and windows of 8..150 bases"""
+    d = descriptor.desc
+    if not (d.gap_open == 2 and d.gap_extend == 2 and 8 <= d.max_align_length <= 150):
+        return False
+    m = d.adapter_matrix
+    for t in range(4):
+        for q in range(4):
+            if m[t * 7 + q] != (5 if t == q else -2):
+                return False
+    return all(m[4 * 7 + q] == -1 for q in range(4))
+
+
+def _abs_plans(t, sequence):
+    """(struct text, entry points, form mask) of template t's bit-sliced adapter plans: two stages when they fit (form 1),
+    else four wide stages (form 4); four narrow stages for medium batches when every stage holds <= 13 columns (form 2)"""
+    seq = sequence.upper()
+    text, entry, forms = [], [], 0
+    two = abs_plan.emit_plan("QABJ_T%d" % t, [seq], "template %d" % t)
+    if two:
+        text.append(two)
+        entry.append('extern "C" __global__ void __launch_bounds__(128, 2) qj_abs_%d(qk::AbsArgs a) { qk::abs_body<qabs::QABJ_T%d>(a); }\n' % (t, t))
+        forms |= 1
+    else:
+        wide = abs_plan.emit_multi("QAWJ_T%d" % t, [seq], "template %d (wide stages)" % t, maxc=abs_plan.MW_MAX_COLUMNS)
+        if wide:
+            text.append(wide)
+            entry.append('extern "C" __global__ void __launch_bounds__(256, 2) qj_absw_%d(qk::AbsArgs a) { qk::abs_ms_body<qabs::QAWJ_T%d>(a); }\n' % (t, t))
+            forms |= 4
+    ms = abs_plan.emit_multi("QAMJ_T%d" % t, [seq], "template %d" % t)
+    if ms:
+        text.append(ms)
+        entry.append('extern "C" __global__ void __launch_bounds__(256, 4) qj_absm_%d(qk::AbsArgs a) { qk::abs_ms_body<qabs::QAMJ_T%d>(a); }\n' % (t, t))
+        forms |= 2
+    return "".join(text), entry, forms
+
+
 def generate(descriptor, skip_templates=(), skip_groups=()):
     """(source text, template flags, group flags, pair entries per group) for the templates /
     (template, set) groups of ``descriptor`` that can take static-letter kernels and are not in the
@@ -154,6 +193,8 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
     grp_flags = [0] * (2 * MAX_TEMPLATES)
     parts = ['#include "jit_prelude.inc"\n', "namespace qk {\n"]
     entry = []
+    abs_text = []                                            # bit-sliced adapter plans (namespace qabs, after namespace qk)
+    abs_ok = _abs_ok(descriptor) and os.environ.get("QCAT_AMD_JIT_NO_ABS") is None
     entries = [[] for _ in range(2 * MAX_TEMPLATES)]          # per group: (pair case, barcode a, barcode b or -1)
     quads = [[] for _ in range(2 * MAX_TEMPLATES)]            # per group: (quad case, barcodes a, b, c, d, shared column counts)
     for t, lay in enumerate(descriptor.layouts):
@@ -167,6 +208,12 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
             entry.append('extern "C" __global__ void __launch_bounds__(qk::PK_WAVES * 64, QS_ADAPTER_WAVES(%d)) '
                          "qj_am_%d(qk::MiddleAdapterArgs a) { qk::adapter_middle_body<%d, qk::QACJ_%d>(a); }\n" % (m, t, m, t))
             tpl_flags[t] = 1
+            if abs_ok:                                       # bits 1..3: the forms of its bit-sliced plan (qcat_kit_attach_code)
+                text, ents, forms = _abs_plans(t, lay.sequence)
+                if forms:
+                    abs_text.append(text)
+                    entry.extend(ents)
+                    tpl_flags[t] |= forms << 1
         for s in range(nsets):
             g = t * 2 + s
             bs = lay.get_barcode_set(s)
@@ -247,6 +294,11 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
                              "qj_bs_%d(qk::BsArgs a) { qk::bs_barcode_body<qk::QBSJ_%d>(a); }\n" % (g, g))
                 grp_flags[g] |= 2
     parts.append("}  // namespace qk\n")
+    if abs_text:
+        # the kernel bodies of kernels_abs.inc without the built-in kits' plans, then this kit's plans
+        parts.append('#define QCAT_ABS_NO_BUILTIN 1\n#include "kernels_abs.inc"\n'
+                     "#define ABS_COPY4(D, S) do { (D)[0] = (S)[0]; (D)[1] = (S)[1]; (D)[2] = (S)[2]; (D)[3] = (S)[3]; } while (0)\n"
+                     "namespace qabs {\n" + "".join(abs_text) + "}  // namespace qabs\n")
     return "".join(parts + entry), tpl_flags, grp_flags, entries, [[q[:5] for q in g] for g in quads]
 
 

@@ -12,7 +12,7 @@ import threading
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MODE_EPI2ME, MODE_DUAL, MODE_SIMPLE = 0, 1, 2
 ENDS_5P, ENDS_BOTH = 1, 3
 MAX_TEMPLATES = 16
@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("QCAT_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "li
 
 class BarcodeSetDesc(C.Structure):
     _fields_ = [("sequences", C.c_char_p), ("ids", C.POINTER(C.c_int32)),
-                ("n", C.c_int32), ("barcode_len", C.c_int32)]
+                ("n", C.c_int32), ("barcode_len", C.c_int32), ("lengths", C.POINTER(C.c_int32))]
 
 
 class TemplateDesc(C.Structure):
@@ -138,16 +138,22 @@ class KitDescriptor(object):
                     sd.n = 0
                     sd.barcode_len = 0
                     continue
-                # the native layer takes a set as n rows of ONE length (qcat_barcode_set_desc); the reference aligns
-                # every barcode with its own length (scanner_base.py:112-117), so lists of unequal length -- only a
-                # user FASTA in simple mode can hold them -- are refused here instead of being sliced wrongly
-                lens = set(len(b.sequence) for b in bset)
-                if len(lens) != 1 or 0 in lens:
-                    raise RuntimeError("barcode set %d of %s holds barcodes of different lengths (%s): the device "
-                                       "path needs one length per set"
-                                       % (i + 1, getattr(lay, "kit", "the barcode list"),
-                                          ", ".join(str(n) for n in sorted(lens))))
-                blob = "".join(b.sequence for b in bset).encode("latin-1", "replace")
+                # a set travels as n rows of barcode_len letters; the reference aligns every barcode with its own length
+                # (scanner_base.py:112-117), and a user FASTA in simple mode may hold barcodes of unequal length: rows padded
+                # to the longest, the real lengths beside them (qcat_barcode_set_desc.lengths, ABI 4).  A template's
+                # placeholder has ONE length (layout.py:55-61), so the other modes refuse such a list -- ValueError: the
+                # driver logs it and exits cleanly (cli.main)
+                lens = [len(b.sequence) for b in bset]
+                if 0 in lens:
+                    raise ValueError("barcode set %d of %s holds an empty barcode" % (i + 1, getattr(lay, "kit", "the barcode list")))
+                width = max(lens)
+                ragged = min(lens) != width
+                if ragged and mode != "simple":
+                    raise ValueError("barcode set %d of %s holds barcodes of different lengths (%s): only simple mode "
+                                     "(a barcode FASTA) aligns every barcode with its own length"
+                                     % (i + 1, getattr(lay, "kit", "the barcode list"),
+                                        ", ".join(str(n) for n in sorted(set(lens)))))
+                blob = "".join(b.sequence + "-" * (width - len(b.sequence)) for b in bset).encode("latin-1", "replace")
                 ids = (C.c_int32 * len(bset))()
                 for j, b in enumerate(bset):
                     if b.id not in self.id_slots:
@@ -158,7 +164,11 @@ class KitDescriptor(object):
                 sd.sequences = blob
                 sd.ids = ids
                 sd.n = len(bset)
-                sd.barcode_len = len(bset[0].sequence)
+                sd.barcode_len = width
+                if ragged:
+                    larr = (C.c_int32 * len(bset))(*lens)
+                    self._keep.append(larr)
+                    sd.lengths = larr
         self._templates = tarr
 
         d = KitDesc()
@@ -203,7 +213,8 @@ class KitInfo(C.Structure):
     """qcat_kit_info (include/qcat_hip.h): which kernels a prepared kit runs."""
     _fields_ = [("packed", C.c_int32), ("barcode_f16", C.c_int32), ("adapter_f16", C.c_int32),
                 ("n_templates", C.c_int32), ("n_static_templates", C.c_int32),
-                ("n_groups", C.c_int32), ("n_static_groups", C.c_int32), ("bitslice_groups", C.c_int32)]
+                ("n_groups", C.c_int32), ("n_static_groups", C.c_int32), ("bitslice_groups", C.c_int32),
+                ("bitslice_templates", C.c_int32)]
 
 
 def pack_reads(read_sequences):

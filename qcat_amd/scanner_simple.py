@@ -41,7 +41,8 @@ class _SimpleLayout(object):
         return -1
 
     def get_barcode_length(self, i):
-        return len(self.barcode_set_1[0].sequence) if i == 0 and self.barcode_set_1 else 0
+        # (the longest barcode: a FASTA may hold barcodes of unequal length, native.KitDescriptor pads the rows)
+        return max(len(b.sequence) for b in self.barcode_set_1) if i == 0 and self.barcode_set_1 else 0
 
     def get_barcode_set(self, i):
         return self.barcode_set_1 if i == 0 else None

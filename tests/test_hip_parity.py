@@ -422,8 +422,13 @@ def test_bit_sliced_barcode_kernels_equal_the_binary16_kernels_and_the_oracle(mo
     bases, offsets = native.pack_reads(reads)
     got = {}
     monkeypatch.setenv("QCAT_HIP_BITSLICE_MIN", "16384")     # (the path is for batches that fill the chip: force it here)
-    for variant in ("static letters", "side streams", "letters from memory", "off"):
-        if variant == "side streams":                            # (the arrangement of big batches: one stream per target family)
+    for variant in ("static letters", "no producer wave", "side streams", "letters from memory", "off"):
+        if variant == "no producer wave":                        # (units with an idle wave: the shared columns as a phase of their own)
+            monkeypatch.setenv("QCAT_HIP_BS_NO_SOLO", "1")
+            monkeypatch.setenv("QCAT_HIP_LEFTOVER_SIDE", "0")
+        elif variant == "side streams":                          # (the arrangement of big batches: one stream per target family)
+            monkeypatch.delenv("QCAT_HIP_BS_NO_SOLO")
+            monkeypatch.delenv("QCAT_HIP_LEFTOVER_SIDE")
             monkeypatch.setenv("QCAT_HIP_BS_SIDE", "1")
         elif variant == "letters from memory":
             monkeypatch.delenv("QCAT_HIP_BS_SIDE")
@@ -551,7 +556,8 @@ def test_bit_sliced_shapes_of_custom_kits(letters, tmp_path, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,kit,ends", [("epi2me", "PBC096", native.ENDS_BOTH), ("epi2me", "NBD103/NBD104", native.ENDS_5P),
                                            ("epi2me", "PBK004/LWB001", native.ENDS_BOTH), ("epi2me", None, native.ENDS_BOTH),
-                                           ("epi2me", "RBK001", native.ENDS_BOTH), ("dual", None, native.ENDS_BOTH)])
+                                           ("epi2me", "RBK001", native.ENDS_BOTH), ("dual", None, native.ENDS_BOTH),
+                                           ("epi2me", "VMK001", native.ENDS_BOTH)])       # (102 columns: four wide stages, round 4)
 def test_bit_sliced_adapter_kernels_equal_the_binary16_kernels_and_the_oracle(mode, kit, ends, monkeypatch):
     """The bit-sliced adapter kernels (kernels_abs.inc) take the full-length windows of plain A/C/G/T of a big batch, the
     binary16 kernels of the same kit the 128-end tiles that hold anything else.  A debug scan of a mixed batch (plain

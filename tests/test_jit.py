@@ -37,6 +37,11 @@ def _custom_kits(folder):
     # (the dual scanner only looks at layouts of the kit named DUAL, like the reference)
     os.makedirs(os.path.join(folder, "dual"), exist_ok=True)
     _write_kit(os.path.join(folder, "dual"), "DUAL_5p", "DUAL", "AGGTTAC" + "N" * 24 + "CAGCACCTGGTGATG" + "N" * 24 + "TTAACCTTTCTGTTGG", s1, s2)
+    # a template too long for two stages of 52 columns (100 columns: four wide stages, like VMK001's 102) and a short one
+    # whose four stages hold <= 13 columns (40 columns: the medium-batch form)
+    long_seq = "".join(rng.choice("ACGT") for _ in range(40)) + "N" * 24 + "".join(rng.choice("ACGT") for _ in range(36))
+    _write_kit(folder, "L_5p", "LONGKIT", long_seq, bcs[:12])
+    _write_kit(folder, "L_3p", "LONGKIT", "GGTGCTG" + "N" * 24 + "TTAACCTAC", bcs[:12])
 
 
 @needs_hipcc
@@ -51,6 +56,13 @@ def test_generated_unit_compiles_and_binds_everything(tmp_path):
         assert info["n_static_groups"] == info["n_groups"] == ng
         # ... and the bit-sliced kernels of every group have the kit's letters compiled in (qj_bs_<group>)
         assert plain["bitslice_groups"] == ng and info["bitslice_groups"] == ng * 0x10001
+        # ... and every template got a bit-sliced ADAPTER plan of two stages (qj_abs_<t>, round 4)
+        assert plain["bitslice_templates"] == 0 and info["bitslice_templates"] == nt
+    det = scanner.factory(mode="epi2me", kit="LONGKIT", kit_folder=str(tmp_path))
+    info = native.NativeKit(det.descriptor(), jit=True).describe()
+    # sorted by file name: L_3p (40 columns: two stages AND four narrow ones), L_5p (100 columns: four wide stages only)
+    assert [len(l.sequence) for l in det.layouts] == [40, 100]
+    assert info["bitslice_templates"] == 1 + 0x100 + 0x10000
 
 
 @pytest.mark.skipif(jit.hiprtc() is None or jit.hipcc_path() is None, reason="needs both libhiprtc and hipcc")
@@ -65,7 +77,7 @@ def test_hiprtc_and_hipcc_both_produce_loadable_units(tmp_path, monkeypatch):
     b = jit._compile_hipcc(source)
     for blob in (a, b):
         assert blob[:4] in (b"\x7fELF", b"__CL") and len(blob) > 10000      # code object or clang offload bundle
-        for sym in (b"qj_ad_0", b"qj_am_0", b"qj_bc_0", b"qj_bc_1", b"qj_bs_0", b"qj_bs_1"):
+        for sym in (b"qj_ad_0", b"qj_am_0", b"qj_bc_0", b"qj_bc_1", b"qj_bs_0", b"qj_bs_1", b"qj_abs_0"):
             assert sym in blob
     monkeypatch.setenv("QCAT_AMD_JIT_COMPILER", "hipcc")
     assert jit.compiler() == "hipcc"
@@ -198,3 +210,40 @@ def test_generated_kernels_match_table_kernels_and_oracle(tmp_path, mode, kit, t
     assert np.array_equal(out[1][3], o_cnt) and np.array_equal(out[1][2], o_rows)
     if middle:
         assert (np.frombuffer(out[1][0], dtype=native.RESULT_DTYPE)["exit_status"] == 997).sum() > 10
+
+
+@pytest.mark.gpu
+@needs_hipcc
+@pytest.mark.parametrize("mode,kit,t5,t3", [("epi2me", "CUSTOM", 0, 1), ("dual", None, 0, -1), ("epi2me", "LONGKIT", 1, 0)])
+def test_generated_bit_sliced_adapter_plans_match_the_oracle(tmp_path, monkeypatch, mode, kit, t5, t3):
+    """Round 4: a custom kit's templates get bit-sliced ADAPTER plans at run time (qcat_amd/abs_plan.py through jit.py:
+    two stages, four narrow stages for medium batches, four wide stages for a template too long for two).  A debug
+    scan of a mixed batch with the path forced (either pipeline form) against the oracle: per-template raw score and
+    end_query of every window, every per-barcode row, the records, the counts."""
+    _custom_kits(str(tmp_path))
+    det = scanner.factory(mode=mode, kit=kit, kit_folder=str(tmp_path) if kit else os.path.join(str(tmp_path), "dual"))
+    reads = synth.synth_batch(5000, 77, det.layouts, t5, t3, error_rate=0.08)
+    for i in range(0, len(reads), 9):
+        reads[i] = reads[i][:30 + (i % 200)] if i % 2 else reads[i][:50] + "N" + reads[i][51:]
+    reads += ["", "ACGTN" * 40, ("ACG" * 80)[:170]]
+    d = det.descriptor()
+    o_recs, o_cnt, o_traces, o_rows = oracle_lib.scan(d, reads, counts=True, trace=True, rows=True, threads=8)
+    kit_h = native.NativeKit(d, jit=True)
+    assert kit_h.describe()["bitslice_templates"] > 0
+    bases, offsets = native.pack_reads(reads)
+    monkeypatch.setenv("QCAT_HIP_ADAPTER_BITSLICE_MIN", "1")
+    for stages in ("2", "4"):
+        monkeypatch.setenv("QCAT_HIP_ABS_STAGES", stages)
+        ctx = native.NativeContext(0)
+        lib = native.HipLibrary.get().lib
+        native.HipLibrary.get().check(lib.qcat_ctx_set_timing(ctx.handle, 1))
+        cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+        recs, traces, rows = ctx.scan(kit_h, bases, offsets, counts=cnt, trace=True, rows=True)
+        import ctypes as C
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        ran = [names[i].decode() for i in range(lib.qcat_ctx_last_timing(ctx.handle, names, ms, 16))]
+        assert "k_adapter_bitslice" in ran, ran
+        for n in ("tpl_raw", "tpl_end"):
+            assert np.array_equal(traces[n], o_traces[n]), (stages, n)
+        assert recs.tobytes() == o_recs.tobytes() and np.array_equal(rows, o_rows) and np.array_equal(cnt, o_cnt)

@@ -1,5 +1,6 @@
 """Oracle vs the outputs of the reference's own Python (tests/golden/golden_vectors.json,
 made by tests/golden/make_golden.py).  Pins everything above the parasail call.  CPU only."""
+import json
 import os
 
 import numpy as np
@@ -209,3 +210,43 @@ def test_mapped_code_matches_known_cases():
     x6 = oracle_lib.sg_stats("ACGTXACGT", "ACGTRACGT", 1, 1, bt, rule=native.STATS_PARASAIL6)
     x5 = oracle_lib.sg_stats("ACGTXACGT", "ACGTRACGT", 1, 1, bt, rule=native.STATS_PARASAIL5)
     assert x6[:3] == x5[:3] and x6[3] == 8 and x5[3] == 9
+
+
+def _ragged_entries():
+    with open(os.path.join(helpers.GOLDEN, "simple_ragged.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_simple_mode_barcodes_of_unequal_length_against_the_reference(i, tmp_path):
+    """A barcode FASTA whose barcodes have different lengths (simple mode): the reference aligns every barcode with its
+    own length and normalises by it (qcat/scanner_base.py:108-119).  Fixture = the unmodified reference's
+    detect_barcode outputs (tests/golden/make_simple_ragged_golden.py); here the oracle through the descriptor's
+    per-barcode lengths (qcat_barcode_set_desc.lengths, ABI 4)."""
+    entry = _ragged_entries()[i]
+    fa = tmp_path / "ragged.fasta"
+    fa.write_text(entry["fasta"])
+    det = scanner.factory(mode="simple", kit=str(fa))
+    assert [len(b.sequence) for b in det.barcodes] == entry["lengths"] and len(set(entry["lengths"])) > 1
+    reads = helpers.simple_reads(entry)
+    recs = oracle_lib.scan(det.descriptor(), reads)
+    got = [helpers.simple_record_as_golden(r, det.barcodes) for r in recs]
+    assert got == entry["results"]
+    dens = set(int(r["score_den"]) for r in recs if r["barcode_idx"] >= 0)
+    assert len(dens) > 2                                   # winners of several lengths: the denominators travel per barcode
+
+
+def test_unequal_barcode_lengths_outside_simple_mode_are_a_value_error():
+    """a template's placeholder has one length (layout.py:55-61): epi2me / dual kits refuse such a set with ValueError,
+    which the driver logs (cli.main) instead of a traceback"""
+    from qcat_amd import config as qconfig, native
+    det = scanner.factory(mode="epi2me", kit="NBD103/NBD104")
+    lay = det.layouts[0]
+    import copy
+    lay2 = copy.copy(lay)
+    bs = list(lay.get_barcode_set(0))
+    from qcat_amd.adapters import Barcode
+    bs[1] = Barcode(bs[1].name, bs[1].id, bs[1].sequence[:20], bs[1].fwd_strand)
+    lay2.barcode_set_1 = bs
+    with pytest.raises(ValueError):
+        native.KitDescriptor([lay2], qconfig.qcatConfig(), mode="epi2me")

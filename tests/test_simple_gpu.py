@@ -1,6 +1,8 @@
 """BarcodeScannerSimple on the GPU (QCAT_MODE_SIMPLE; qcat/scanner_simple.py:41-91):
 against the reference's own detect_barcode outputs (golden "simple") through the Python drop-in, and
 record-for-record / trace-for-trace against the oracle on larger mixed batches."""
+import os
+
 import numpy as np
 import pytest
 
@@ -78,3 +80,30 @@ def test_simple_barcodes_from_a_fasta_file(tmp_path):
     assert res["trim5p"] == 63 + 24 - 1 and res["trim3p"] == len(read)
     with pytest.raises(TypeError):
         scanner.factory(mode="simple", kit=None)
+
+
+@pytest.mark.parametrize("i", [0, 1])
+def test_simple_barcodes_of_unequal_length_match_the_reference_and_the_oracle(i, tmp_path):
+    """A barcode FASTA with barcodes of 16 to 29 letters: every barcode aligned with its own length and normalised by
+    it (qcat/scanner_base.py:108-119; round 3 refused such a list).  The drop-in's dicts against the unmodified
+    reference's (tests/golden/simple_ragged.json), the device records against the oracle on a larger batch."""
+    import json
+    with open(os.path.join(helpers.GOLDEN, "simple_ragged.json")) as fh:
+        entry = json.load(fh)[i]
+    fa = tmp_path / "ragged.fasta"
+    fa.write_text(entry["fasta"])
+    det = scanner.factory(mode="simple", kit=str(fa))
+    reads = helpers.simple_reads(entry)
+    cfg = config.qcatConfig()
+    for read, want in zip(reads, entry["results"]):
+        got = det.detect_barcode(read, qcat_config=cfg)
+        assert (got["barcode"].name if got["barcode"] else None) == want["barcode_name"]
+        assert float(got["barcode_score"]).hex() == want["score_hex"]
+        assert (got["adapter_end"], got["trim5p"], got["trim3p"], got["exit_status"]) == (
+            want["adapter_end"], want["trim5p"], want["trim3p"], want["exit_status"])
+    many = reads * 20
+    d = det.descriptor()
+    cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+    got = native.NativeContext(0).scan(native.NativeKit(d), *native.pack_reads(many), counts=cnt)
+    want, want_cnt = oracle_lib.scan(d, many, counts=True, threads=8)
+    assert got.tobytes() == want.tobytes() and np.array_equal(cnt, want_cnt)
