@@ -412,6 +412,7 @@ struct qcat_ctx {
     uint8_t* mid_generic = nullptr; size_t cap_mid_generic = 0;
     uint32_t* mid_slot = nullptr; size_t cap_mid_slot = 0;
     uint32_t* mid_sorted = nullptr; int32_t* mid_len = nullptr; int32_t* mid_fallback = nullptr;
+    uint32_t* mid_win2 = nullptr; uint8_t* mid_wspec = nullptr;   // the M-ends' first window at two bits per code + flags (k_mid_windows)
     EndRec* mid_recs = nullptr; AdapterBest* mid_bests = nullptr;
     size_t cap_mid_slots = 0, cap_mid_bests = 0;
     uint32_t last_n_reads = 0;
@@ -468,6 +469,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     pipeline_free(c->pipe);
     (void)hipFree(c->mid_tables); (void)hipFree(c->mid_generic); (void)hipFree(c->mid_slot); (void)hipFree(c->mid_sorted);
     (void)hipFree(c->mid_len); (void)hipFree(c->mid_fallback); (void)hipFree(c->mid_recs); (void)hipFree(c->mid_bests);
+    (void)hipFree(c->mid_win2); (void)hipFree(c->mid_wspec);
     if (c->ev_ready) for (int r = 0; r < qcat_ctx::TIME_RING; ++r) for (int i = 0; i <= MAX_TIMED; ++i) (void)hipEventDestroy(c->evr[r][i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -527,7 +529,11 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     if ((rc = grow(&c->mid_slot, &c->cap_mid_slot, (size_t)n))) return rc;
     if (slots > c->cap_mid_slots) {
         (void)hipFree(c->mid_sorted); (void)hipFree(c->mid_len); (void)hipFree(c->mid_fallback); (void)hipFree(c->mid_recs);
+        (void)hipFree(c->mid_win2); (void)hipFree(c->mid_wspec);
         c->mid_sorted = nullptr; c->mid_len = nullptr; c->mid_fallback = nullptr; c->mid_recs = nullptr; c->cap_mid_slots = 0;
+        c->mid_win2 = nullptr; c->mid_wspec = nullptr;
+        HIPCHK(hipMalloc((void**)&c->mid_win2, (slots * WIN2_WORDS + 64) * 4));
+        HIPCHK(hipMalloc((void**)&c->mid_wspec, slots + 4));
         HIPCHK(hipMalloc((void**)&c->mid_sorted, slots * 4));
         HIPCHK(hipMalloc((void**)&c->mid_len, slots * 4));
         HIPCHK(hipMalloc((void**)&c->mid_fallback, slots * 4));
@@ -548,7 +554,19 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     // adapter phase: one launch per template (tiles of other kits record "did not compete"), the
     // launches of a scan run concurrently
     PackedScratch* sc = &c->packed;
-    sc->wspec = nullptr;                                  // interiors: no letter flags, no bit-sliced classes
+    // round 4: the interiors' first window at two bits per code, so that their whole-window barcode jobs -- nearly all of
+    // them -- run on the bit-sliced barcode kernels (QCAT_HIP_MIDDLE_NO_BITSLICE=1: binary16 kernels as before)
+    const bool mid_bs = getenv("QCAT_HIP_MIDDLE_NO_BITSLICE") == nullptr;
+    if (mid_bs) {
+        HIPCHK(hipMemsetAsync(c->mid_wspec, 0, slots + 4, st));
+        const uint64_t wthreads = (uint64_t)slots * WIN2_WORDS;
+        hipLaunchKernelGGL(k_mid_windows, dim3((uint32_t)((wthreads + 255) / 256)), dim3(256), 0, st, b->bases, b->offsets, hk.max_align,
+                           c->mid_sorted, (uint32_t)slots, c->mid_win2, c->mid_wspec);
+    }
+    sc->wspec = mid_bs ? c->mid_wspec : nullptr;          // (null: no letter flags, no bit-sliced classes)
+    sc->win2 = mid_bs ? c->mid_win2 : nullptr;
+    sc->win = c->win;                                     // (never read: the job regions come from win2, `lazy`)
+    sc->lazy = mid_bs;
     sc->slim = false;                                     // ... and the barcode results stay in the interior's own records
     if ((rc = packed_prepare(st, hk, (uint32_t)slots, sc))) return set_err(rc, packed_last_error());
     const uint32_t tiles = (uint32_t)(slots / PK_TILE);
@@ -560,7 +578,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     {
         const uint32_t fblocks = (uint32_t)std::min<uint64_t>((slots + 255) / 256, 2048);
         hipLaunchKernelGGL(k_adapter_finish, dim3(fblocks), dim3(256), 0, st, kp.kit, c->mid_len, (uint32_t)slots,
-                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1, (const uint8_t*)nullptr, sc->jobinfo, (int2*)nullptr, (uint32_t*)nullptr);
+                           c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1, (const uint8_t*)sc->wspec, sc->jobinfo, (int2*)nullptr, (uint32_t*)nullptr);
     }
     const int nsets = hk.mode == QCAT_MODE_DUAL ? 2 : 1;
     rc = packed_barcode(st, kp, hk, (uint32_t)slots, c->mid_recs, sc, [&](uint32_t max_tiles, const BsPlan*) {
@@ -650,12 +668,28 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
                                         c->packed.abs_planes, c->packed.abs_valid, reinterpret_cast<uint8_t*>(tile_any + tiles), tile_any);
             c->packed.abs_ready = (uint32_t)n_ends;
             c->win2_valid = false;                       // (that kernel does not make the two-bit copy)
+            c->packed.lazy = false;
         } else {
             c->win2_valid = true;
+            // lazy byte windows (round 4): a kit whose every template runs a generated kernel reads plain windows at two
+            // bits per code everywhere (dev_window16), so the byte windows -- 3.3 of the pack kernel's 4.1 GB of stores per
+            // 10 M reads -- are written for the flagged ends only (k_expand_special; QCAT_HIP_EAGER_BYTES=1: all of them)
+            bool lazy = use_packed && hk.mode != QCAT_MODE_SIMPLE && hk.adapter_f16 && getenv("QCAT_HIP_NO_STATIC") == nullptr &&
+                        getenv("QCAT_HIP_NO_STATIC_ADAPTER") == nullptr && getenv("QCAT_HIP_EAGER_BYTES") == nullptr;
+            for (int t = 0; t < hk.nt && lazy; ++t) lazy = hk.tpl[t].static_kernel >= 0;
+            c->packed.lazy = lazy;
             hipLaunchKernelGGL(k_pack_windows, dim3(blocks), dim3(256), 0, c->stream,
-                               b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen, c->wspec, c->win2);
+                               b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen, c->wspec, c->win2, lazy ? 1 : 0);
+            if (lazy) hipLaunchKernelGGL(k_expand_special, dim3(blocks), dim3(256), 0, c->stream,
+                                         b->bases, b->offsets, n, ends, hk.max_align, c->wspec, c->win);
         }
         mark(c, "k_pack_windows");
+    }
+    if (resume_kit_mask >= 0 && g_fill_defer && use_packed && c->packed.slices_single && hk.mode != QCAT_MODE_SIMPLE) {
+        // (a resumed scan -- the second pass of a kit-auto batch: its job tables' fills with the count vector's, one launch)
+        c->packed.slim = use_packed && !debug && getenv("QCAT_HIP_NO_SLIM") == nullptr;
+        if ((rc = packed_prepare(c->stream, hk, (uint32_t)n_ends, &c->packed))) { g_fill_defer = false; g_fill.n = 0; return set_err(rc, packed_last_error()); }
+        c->packed.prepared = true;
     }
     HIPCHK(packed_fill_flush(c->stream));               // (a resumed scan: the count vector's fill)
     if (hk.mode == QCAT_MODE_SIMPLE && adapter_only) return set_err(QCAT_ERR_ARG, "simple mode has no adapter templates to vote with");
@@ -1305,7 +1339,7 @@ static int vote_resident(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, unsign
     if (rc || !b->n_reads) return rc;
     KitOnDevice* kd = nullptr;
     if ((rc = kit_on_device(kit, c->device, &kd))) return rc;
-    if (!c->vote_buf) HIPCHK(hipMalloc((void**)&c->vote_buf, 2 * MAX_T * 8));
+    if (!c->vote_buf) HIPCHK(hipMalloc((void**)&c->vote_buf, 2 * MAX_T * 8 + 16));        // (+ the chosen kit slot: scan_batch_auto_impl)
     unsigned long long* d = c->vote_buf;
     HIPCHK(hipMemsetAsync(d, 0, MAX_T * 8, c->stream));
     HIPCHK(hipMemsetAsync(d + MAX_T, 0xFF, MAX_T * 8, c->stream));
@@ -1370,10 +1404,19 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
     HIPCHK(packed_fill_flush(c->stream));
     const uint32_t blocks = std::min<uint32_t>((n_reads + 255) / 256, 1024);
     hipLaunchKernelGGL(k_vote, dim3(blocks), dim3(256), 0, c->stream, kd->kit, c->recs, n_reads, d, d + MAX_T);
-    hipLaunchKernelGGL(k_pick_kit, dim3(1), dim3(1), 0, c->stream, kd->kit, d, d + MAX_T, chosen_dev);
+    hipLaunchKernelGGL(k_pick_kit, dim3(1), dim3(64), 0, c->stream, kd->kit, d, d + MAX_T, chosen_dev);
     // pass 2: detect_barcode per read with the voted kit's templates (:714-733): the adapter alignments of the vote are still
     // on the device -- only their merge (the kit slot read from chosen_dev), the barcode phase and the finalisation run now
     c->packed.kit_slot_dev = chosen_dev;
+    if (getenv("QCAT_HIP_DEBUG_VOTE")) {                      // (diagnostics: the choice as the device made it, before the second pass)
+        unsigned long long dv[2 * MAX_T]; int32_t dc = -7;
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(dv, d, sizeof dv, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&dc, chosen_dev, 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[qcat] vote: chosen %d (kit slots %d, templates %d):", dc, hk.n_kit_slots, hk.nt);
+        for (int t = 0; t < hk.nt; ++t) fprintf(stderr, " %llu/slot%d", dv[t], hk.tpl[t].kit_slot);
+        fprintf(stderr, "\n");
+    }
     if ((rc = scan_resident_impl(c, kit, b, false, 0, false, RESUME_KIT_ON_DEVICE))) return drained(rc);
     unsigned long long hv[MAX_T], hf[MAX_T];
     int32_t chosen = -1;

@@ -217,6 +217,22 @@ class KitInfo(C.Structure):
                 ("bitslice_templates", C.c_int32)]
 
 
+try:                                   # optional C helper for the list <-> buffer conversions (csrc/pyglue.c, built by build())
+    if os.environ.get("QCAT_AMD_NO_PYGLUE"):
+        raise ImportError("switched off")
+    from . import _pyglue
+except ImportError:                    # pure-Python fall-backs below
+    _pyglue = None
+
+
+def read_views(read_sequences):
+    """(pointer bytes, length bytes) over the caller's str / bytes objects -- no copy -- for the `_ptrs` entry points, or
+    None (no helper module, or an element that is not an ASCII str / bytes / None: pack_reads then)."""
+    if _pyglue is None or type(read_sequences) is not list:
+        return None
+    return _pyglue.read_views(read_sequences)
+
+
 def pack_reads(read_sequences):
     """list of str/bytes/None -> (uint8 bases, uint64 offsets[n+1])."""
     n = len(read_sequences)
@@ -283,6 +299,7 @@ class HipLibrary(object):
             "qcat_detect_kit": (C.c_int, [vp, vp, vp, vp, u32, vp, vp]),
             "qcat_scan_sequences": (C.c_int, [vp, vp, vp, vp, u32, vp]),
             "qcat_scan_batch_auto": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, C.POINTER(i32), vp, vp]),
+            "qcat_scan_batch_auto_ptrs": (C.c_int, [vp, vp, C.c_char_p, C.c_char_p, u32, vp, vp, C.POINTER(i32), vp, vp]),
             "qcat_batch_upload": (C.c_int, [vp, vp, vp, u32, C.POINTER(vp)]),
             "qcat_batch_synthesize": (C.c_int, [vp, vp, C.POINTER(SynthParams), C.POINTER(vp)]),
             "qcat_batch_destroy": (None, [vp]),
@@ -494,6 +511,18 @@ class NativeContext(object):
         slot = C.c_int32(-1)
         rc = self.hip.lib.qcat_scan_batch_auto(self.handle, kit.handle, bases.ctypes.data, offsets.ctypes.data, n,
                                                out.ctypes.data, None, C.byref(slot), None, None)
+        if rc == -2:
+            return None
+        self.hip.check(rc)
+        return out, int(slot.value)
+
+    def scan_auto_views(self, kit, views, n):
+        """qcat_scan_batch_auto_ptrs over :func:`read_views` of the caller's list (the list must stay alive and unchanged
+        during the call: it does, the caller holds it); returns like :meth:`scan_auto`."""
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        slot = C.c_int32(-1)
+        rc = self.hip.lib.qcat_scan_batch_auto_ptrs(self.handle, kit.handle, views[0], views[1], n,
+                                                    out.ctypes.data, None, C.byref(slot), None, None)
         if rc == -2:
             return None
         self.hip.check(rc)

@@ -261,7 +261,7 @@ class BarcodeScanner(object):
         bidx = recs["barcode_idx"].astype(np.intp)
         key = tuple(id(l) for l in layouts)
         tbl = getattr(self, "_dict_tables", None)
-        if tbl is None or tbl[0] != key:
+        if tbl is None or tbl[0] != key:         # (key, barcode table, adapter table[, the two as plain lists for the C helper])
             width = 1 + max([len(l.get_barcode_set(0) or ()) if l.barcode_set_1 is not None else 0 for l in layouts] + [0])
             bars = np.empty((len(layouts) + 1, width), dtype=object)          # row 0 / column 0: None (index -1)
             for t, lay in enumerate(layouts):
@@ -271,7 +271,13 @@ class BarcodeScanner(object):
             ads = np.empty(len(layouts) + 1, dtype=object)
             ads[1:] = layouts
             tbl = self._dict_tables = (key, bars, ads)
-        _key, bars, ads = tbl
+        bars, ads = tbl[1], tbl[2]
+        if native._pyglue is not None:                                        # the same dicts built in C (csrc/pyglue.c)
+            if len(tbl) < 5:
+                tbl = self._dict_tables = tbl + (bars.tolist(), ads.tolist())
+            got = native._pyglue.records_to_dicts(np.ascontiguousarray(recs), tbl[3], tbl[4])
+            if got is not None:                                               # (None: dual records, a Barcode per pair below)
+                return got
         adapters = ads[aidx + 1].tolist()
         # the same IEEE double expression as scanner_base.py:119: raw * 100.0 / (1.0 * den)
         den = np.maximum(recs["score_den"].astype(np.float64), 1.0)
@@ -407,8 +413,12 @@ class BarcodeScanner(object):
                 or self.scan_middle_adapter):
             return None
         kit = self._native_kit(self.layouts, qcat_config, native.ENDS_BOTH)
-        bases, offsets = native.pack_reads(read_sequences)
-        got = self._context().scan_auto(kit, bases, offsets)
+        views = native.read_views(read_sequences)         # the str objects' own buffers (csrc/pyglue.c), or None
+        if views is not None:
+            got = self._context().scan_auto_views(kit, views, len(read_sequences))
+        else:
+            bases, offsets = native.pack_reads(read_sequences)
+            got = self._context().scan_auto(kit, bases, offsets)
         if got is None:
             return None
         recs, _slot = got

@@ -149,3 +149,33 @@ def test_one_pass_is_cheaper_than_two_calls():
     det._context().scan(sub, bases, offsets); t2 = time.perf_counter()
     assert votes[0].sum() == len(reads)
     assert (t1 - t0) < (t2 - t1), (t1 - t0, t2 - t1)
+
+
+def test_reads_handed_over_as_pointers_give_the_same_dicts(monkeypatch):
+    """Round 4: detect_barcode_batch passes the str objects' own buffers (qcat_scan_batch_auto_ptrs through
+    qcat_amd/_pyglue.so) and builds the dicts in C; without the helper -- or with a read the helper does not take -- the list
+    is packed as before.  All routes: identical dicts; the device-side kit choice (k_pick_kit) equals the host's vote."""
+    if native._pyglue is None:
+        pytest.skip("the optional C helper is not built")
+    det = scanner.factory()
+    cfg = config.qcatConfig()
+    reads = _mixed_batch(det, "PBC096", 4000, 5)
+    quals = [None] * len(reads)
+    fast = det.detect_barcode_batch(reads, quals, cfg)
+    kit_name, want = _two_pass(det, reads, cfg)
+    assert kit_name == "PBC096"
+    _same(fast, want)
+    monkeypatch.setattr(native, "_pyglue", None)                # pure-Python conversions, concatenated upload
+    _same(det.detect_barcode_batch(reads, quals, cfg), want)
+    monkeypatch.undo()
+    mixed = list(reads)
+    mixed[5] = mixed[5].encode()                                # bytes are taken as they are
+    _same(det.detect_barcode_batch(mixed, quals, cfg), want)
+    odd = list(reads)
+    odd[7] = odd[7][:50] + "é" + odd[7][51:]               # not ASCII: the whole list goes the old way
+    got = det.detect_barcode_batch(odd, quals, cfg)
+    _same(got[:7] + got[8:], want[:7] + want[8:])
+    # small batches (< 256 reads take the whole-read upload) and a batch in which nobody votes
+    _same(det.detect_barcode_batch(reads[:100], quals[:100], cfg), _two_pass(det, reads[:100], cfg)[1])
+    empty = det.detect_barcode_batch(["", ""], [None, None], cfg)
+    assert all(r["barcode"] is None for r in empty)

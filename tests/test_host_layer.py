@@ -174,3 +174,47 @@ def test_fastx_parsers_follow_biopython(tmp_path):
     with pytest.raises(SystemExit) as exc:
         list(cli.iter_fastx(str(bad), True, 10))
     assert exc.value.code == 1
+
+
+def test_the_c_helper_builds_the_same_dicts_and_hands_over_the_strings_uncopied():
+    """qcat_amd/_pyglue.so (csrc/pyglue.c): `records_to_dicts` must give exactly the dicts of the Python loop -- same
+    objects from the kit's tables, the same IEEE double for the score -- and `read_views` one (pointer, length) per str /
+    bytes / None, or None for anything it does not take (the caller then packs the list as before).  Dual records (a
+    Barcode per pair of ids) stay on the Python loop."""
+    import ctypes
+    import struct
+    from qcat_amd import native, scanner
+    if native._pyglue is None:
+        pytest.skip("the optional C helper is not built")
+    det = scanner.factory(mode="epi2me", kit=None)
+    rng = np.random.RandomState(5)
+    n = 500
+    recs = np.zeros(n, dtype=native.RESULT_DTYPE)
+    recs["adapter_idx"] = rng.randint(-1, len(det.layouts), n)
+    nb = np.array([len(l.get_barcode_set(0) or ()) for l in det.layouts])
+    recs["barcode_idx"] = np.where(recs["adapter_idx"] >= 0, rng.randint(-1, 12, n) % np.maximum(nb[np.maximum(recs["adapter_idx"], 0)], 1), -1)
+    recs["barcode_idx"][::7] = -1
+    recs["barcode2_idx"] = -1
+    recs["raw_score"] = rng.randint(-5, 47, n); recs["score_den"] = rng.choice([39, 41, 42, 45, 46], n)
+    recs["adapter_end"] = rng.randint(0, 150, n); recs["trim5p"] = rng.randint(0, 150, n); recs["trim3p"] = rng.randint(0, 9000, n)
+    recs["exit_status"] = rng.choice([0, 1, 1002], n)
+    with_c = det._records_to_dicts(recs, det.layouts)
+    glue, native._pyglue = native._pyglue, None
+    try:
+        det._dict_tables = None
+        plain = det._records_to_dicts(recs, det.layouts)
+    finally:
+        native._pyglue = glue
+    assert with_c == plain and len(with_c) == n
+    for a, b in zip(with_c, plain):
+        assert a["barcode"] is b["barcode"] and a["adapter"] is b["adapter"] and list(a) == list(b)
+        assert float(a["barcode_score"]).hex() == float(b["barcode_score"]).hex()
+    recs["barcode2_idx"][3] = 2                                   # a dual record: not the helper's business
+    assert glue.records_to_dicts(np.ascontiguousarray(recs), [[None]], [None]) is None
+    # read_views: the objects' own buffers
+    reads = ["ACGT" * 5, b"TTTT", None, ""]
+    ptrs, lens = native.read_views(reads)
+    p = struct.unpack("<4Q", ptrs)
+    assert struct.unpack("<4Q", lens) == (20, 4, 0, 0) and p[2] == 0
+    assert ctypes.string_at(p[0], 20) == b"ACGT" * 5 and ctypes.string_at(p[1], 4) == b"TTTT"
+    assert native.read_views(["ACGT", "é"]) is None and native.read_views(["ACGT", 7]) is None and native.read_views(("A",)) is None
