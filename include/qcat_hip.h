@@ -381,8 +381,10 @@ int  qcat_ctx_set_timing(qcat_ctx* ctx, int enabled);
  * (:527-530), TSV rows (:408-442) and the per-barcode / annotated FASTQ writers (:309-358).  The histogram (:366-383)
  * stays with the caller: it gets the records and the skipped flags back.
  * Only plain four-line ASCII FASTQ files qualify (one title, one sequence, one '+', one quality line per read, no '\r',
- * no trailing blanks, no byte >= 0x80): qcat_fastq_open answers QCAT_ERR_UNSUPPORTED for anything Biopython would read
- * differently, and the caller's own parser takes the file. */
+ * no trailing blanks, no byte >= 0x80) and -- round 4 -- plain two-line FASTA files ('>' title, ONE sequence line per read;
+ * the writers then produce FASTA, cli.py:340-346): qcat_fastq_open decides by the first byte like the driver
+ * (cli.py:248-262) and answers QCAT_ERR_UNSUPPORTED for anything Biopython would read differently (wrapped sequences,
+ * blank lines ...), and the caller's own parser takes the file. */
 typedef struct qcat_fastq qcat_fastq;
 int  qcat_fastq_open(const char* path, qcat_fastq** out, uint64_t* n_reads, uint64_t* n_bytes);
 void qcat_fastq_close(qcat_fastq* f);

@@ -368,10 +368,10 @@ def qcat_cli(reads_fq, kit, mode, nobatch, out, min_qual, tsv, output, threads, 
     fastq = is_fastq(reads_fq)
     stream = open(output, "w") if output else sys.stdout
     native_done = None
-    if fastq and reads_fq and not middle_adapter and not filter_barcodes and mode in ("epi2me", "dual") \
+    if reads_fq and not middle_adapter and not filter_barcodes and mode in ("epi2me", "dual") \
             and not os.environ.get("QCAT_AMD_NO_NATIVE_FASTQ"):
-        # plain four-line FASTQ files go through the native ingest / egress (qcat_fastq_demux): same outputs, no Python
-        # string per read; anything else (FASTA, stdin, wrapped or odd records, rare options) stays on the loop below
+        # plain four-line FASTQ files and plain two-line FASTA files go through the native ingest / egress (qcat_fastq_demux):
+        # same outputs, no Python string per read; anything else (stdin, wrapped or odd records, rare options) stays on the loop below
         native_done = _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_length, qcat_config, tsv_stream)
     if native_done is not None:
         barcode_dist, adapter_dist, total_reads, skipped_reads = native_done

@@ -23,6 +23,13 @@ def sha(path):
         return hashlib.sha256(fh.read()).hexdigest()
 
 
+def fasta_of_fastq(path):
+    """the plain two-line FASTA of a four-line FASTQ file: '>' + title, sequence"""
+    with open(path) as fh:
+        lines = fh.read().split("\n")
+    return "".join(">" + lines[i][1:] + "\n" + lines[i + 1] + "\n" for i in range(0, len(lines) - 3, 4))
+
+
 def main():
     make_golden.install_standins()
     make_golden.import_reference()
@@ -69,6 +76,19 @@ def main():
     jobs.append((cfg1, "config1_lwb001_193.fastq",
                  {"tag": "dir-auto-readme", "kit": "auto", "mode": "epi2me", "nobatch": False, "tsv": False, "trim": False, "min_len": 100, "dir": True}))
     file_kits_all["config1_lwb001_193.fastq"] = synth.CONFIG1["kit"]
+    # FASTA input (qcat/cli.py:235-306 reads it with SimpleFastaParser, the writers then produce FASTA): the plain two-line
+    # FASTA of a shipped FASTQ file, derived here and in the test by fasta_of_fastq (not committed)
+    only_fasta = "--only-fasta" in sys.argv
+    fa = os.path.join(tmpd, "fasta_of_nbd103.fasta")
+    with open(fa, "w") as fh:
+        fh.write(fasta_of_fastq(os.path.join(data, "nbd103.fastq")))
+    if only_fasta:
+        jobs = []
+    jobs += [(fa, "fasta_of_nbd103.fasta", v) for v in variants if v["tag"] in ("tsv-auto-batch", "dir-auto-trim", "stream-kit-trim-minlen1000")]
+    file_kits_all["fasta_of_nbd103.fasta"] = file_kits["nbd103.fastq"]
+    if only_fasta:
+        with open(os.path.join(HERE, "cli_golden.json")) as fh:
+            runs = [r for r in json.load(fh)["runs"] if not r["file"].startswith("fasta_of_")]
     if only_config1:
         with open(os.path.join(HERE, "cli_golden.json")) as fh:
             runs = [r for r in json.load(fh)["runs"] if not r["file"].startswith("config1_")]

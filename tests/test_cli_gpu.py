@@ -53,6 +53,14 @@ def test_cli_matches_reference_driver(idx, tmp_path):
         reads_fq = str(tmp_path / run["file"])
         with open(reads_fq, "w") as fh:
             fh.write(synth.config1_fastq(scanner.factory(kit=synth.CONFIG1["kit"]).layouts))
+    if run["file"].startswith("fasta_of_"):
+        # FASTA input: the plain two-line FASTA of a shipped FASTQ file, derived as tests/golden/make_cli_golden.py derives it
+        src = os.path.join(helpers.GOLDEN, "data", run["file"][len("fasta_of_"):].replace(".fasta", ".fastq"))
+        with open(src) as fh:
+            lines = fh.read().split("\n")
+        reads_fq = str(tmp_path / run["file"])
+        with open(reads_fq, "w") as fh:
+            fh.write("".join(">" + lines[i][1:] + "\n" + lines[i + 1] + "\n" for i in range(0, len(lines) - 3, 4)))
     try:
         cli.qcat_cli(reads_fq=reads_fq, kit=run["kit"], mode=v["mode"],
                      nobatch=v["nobatch"], out=outdir, min_qual=None, tsv=v["tsv"],

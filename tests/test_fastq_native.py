@@ -63,7 +63,10 @@ def test_parallel_split_of_a_file_with_awkward_quality_lines(tmp_path, monkeypat
     "@r1\nACGT \n+\nIIII\n",                            # trailing blank on the sequence line
     "@r1\nACGT\n+r2\nIIII\n",                           # '+' line with another title
     "@r1\nACGT\n+\nIII\n",                              # quality shorter than the sequence
-    ">r1\nACGT\n",                                      # FASTA
+    ">r1\nAC\nGT\n",                                    # FASTA with a wrapped sequence
+    ">r1\nACGT\n\n>r2\nAC\n",                          # FASTA with a blank line
+    ">r1\n>r2\nAC\n",                                   # FASTA record without a sequence
+    "; comment\n>r1\nACGT\n",                           # something before the first record
     "@r1\nAC\xc3\xa9T\n+\nIIII\n",                      # non-ASCII
     "@r1\nACGT\n+\n",                                   # truncated
 ])
@@ -73,6 +76,26 @@ def test_anything_else_is_left_to_the_python_parser(body, tmp_path):
         fh.write(body)
     with pytest.raises(native.FastqFile.Unsupported):
         native.FastqFile(path)
+
+
+def test_plain_two_line_fasta_indexes_like_the_python_parser(tmp_path, monkeypatch):
+    """Round 4: plain FASTA ('>' title, one sequence line per read) on the native path too -- same records as the Python
+    parser (Biopython's SimpleFastaParser rules, cli._fasta_records), split over several threads, last record without a
+    newline."""
+    rng = random.Random(11)
+    monkeypatch.setenv("QCAT_HOST_THREADS", "4")
+    lines = []
+    for i in range(50000):
+        seq = "".join(rng.choice("ACGTN") for _ in range(rng.randrange(1, 900)))
+        lines += [">read%d" % i + rng.choice(["", " ch=1", "\tcomment with\ttabs", " trailing  "]), seq]
+    path = str(tmp_path / "plain.fasta")
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines))
+    assert os.path.getsize(path) > 4 * (4 << 20)
+    with open(path) as fh:
+        want = [(t, s) for t, s in cli._fasta_records(fh)]
+    got = _index(path)
+    assert len(got) == 50000 and got == want
 
 
 def test_empty_file_and_missing_file(tmp_path):
