@@ -11,10 +11,10 @@
 extern "C" void qcat_abs_launch_planes(unsigned n_tiles, void* stream, const uint32_t* win2, const int32_t* wlen, const uint8_t* wspec,
                                        uint32_t n_ends, int rows, void* planes, uint32_t* valid, uint8_t* need128, uint32_t* tile_any) {
     if (rows == 150)
-        hipLaunchKernelGGL(qk::k_abs_planes<150>, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), win2, wlen, wspec, n_ends, rows,
+        hipLaunchKernelGGL(qk::k_abs_planes<150>, dim3(n_tiles), dim3(qk::ABS_PLANE_WAVES * 64), 0, static_cast<hipStream_t>(stream), win2, wlen, wspec, n_ends, rows,
                            static_cast<uint2*>(planes), valid, need128, tile_any);
     else
-        hipLaunchKernelGGL(qk::k_abs_planes<0>, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), win2, wlen, wspec, n_ends, rows,
+        hipLaunchKernelGGL(qk::k_abs_planes<0>, dim3(n_tiles), dim3(qk::ABS_PLANE_WAVES * 64), 0, static_cast<hipStream_t>(stream), win2, wlen, wspec, n_ends, rows,
                            static_cast<uint2*>(planes), valid, need128, tile_any);
 }
 
@@ -24,10 +24,10 @@ extern "C" void qcat_abs_launch_pack_planes(unsigned n_tiles, void* stream, cons
                                             uint8_t* need128, uint32_t* tile_any) {
     const qk::AbsPackSrc ps{bases, offsets, n_reads, ends};
     if (rows == 150)
-        hipLaunchKernelGGL(qk::k_pack_planes<150>, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), ps, win, wlen, wspec, n_ends, rows,
+        hipLaunchKernelGGL(qk::k_pack_planes<150>, dim3(n_tiles), dim3(qk::ABS_PLANE_WAVES * 64), 0, static_cast<hipStream_t>(stream), ps, win, wlen, wspec, n_ends, rows,
                            static_cast<uint2*>(planes), valid, need128, tile_any);
     else
-        hipLaunchKernelGGL(qk::k_pack_planes<0>, dim3(n_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), ps, win, wlen, wspec, n_ends, rows,
+        hipLaunchKernelGGL(qk::k_pack_planes<0>, dim3(n_tiles), dim3(qk::ABS_PLANE_WAVES * 64), 0, static_cast<hipStream_t>(stream), ps, win, wlen, wspec, n_ends, rows,
                            static_cast<uint2*>(planes), valid, need128, tile_any);
 }
 

@@ -37,9 +37,10 @@ def _custom_kits(folder):
     # (the dual scanner only looks at layouts of the kit named DUAL, like the reference)
     os.makedirs(os.path.join(folder, "dual"), exist_ok=True)
     _write_kit(os.path.join(folder, "dual"), "DUAL_5p", "DUAL", "AGGTTAC" + "N" * 24 + "CAGCACCTGGTGATG" + "N" * 24 + "TTAACCTTTCTGTTGG", s1, s2)
-    # a template too long for two stages of 52 columns (100 columns: four wide stages, like VMK001's 102) and a short one
-    # whose four stages hold <= 13 columns (40 columns: the medium-batch form)
-    long_seq = "".join(rng.choice("ACGT") for _ in range(40)) + "N" * 24 + "".join(rng.choice("ACGT") for _ in range(36))
+    # a template that two stages of <= 52 columns cannot hold (102 columns with the barcode near the front, like VMK001: the
+    # first stage has to end before the barcode's border -- four wide stages) and a short one whose four stages hold <= 13
+    # columns (40 columns: the medium-batch form)
+    long_seq = "".join(rng.choice("ACGT") for _ in range(20)) + "N" * 24 + "".join(rng.choice("ACGT") for _ in range(58))
     _write_kit(folder, "L_5p", "LONGKIT", long_seq, bcs[:12])
     _write_kit(folder, "L_3p", "LONGKIT", "GGTGCTG" + "N" * 24 + "TTAACCTAC", bcs[:12])
 
@@ -60,8 +61,8 @@ def test_generated_unit_compiles_and_binds_everything(tmp_path):
         assert plain["bitslice_templates"] == 0 and info["bitslice_templates"] == nt
     det = scanner.factory(mode="epi2me", kit="LONGKIT", kit_folder=str(tmp_path))
     info = native.NativeKit(det.descriptor(), jit=True).describe()
-    # sorted by file name: L_3p (40 columns: two stages AND four narrow ones), L_5p (100 columns: four wide stages only)
-    assert [len(l.sequence) for l in det.layouts] == [40, 100]
+    # sorted by file name: L_3p (40 columns: two stages AND four narrow ones), L_5p (102 columns: four wide stages only)
+    assert [len(l.sequence) for l in det.layouts] == [40, 102]
     assert info["bitslice_templates"] == 1 + 0x100 + 0x10000
 
 
