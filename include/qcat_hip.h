@@ -365,6 +365,12 @@ void* qcat_ctx_results_devptr(qcat_ctx* ctx);
  * without a host synchronisation. */
 void* qcat_ctx_stream(qcat_ctx* ctx);
 
+/* how many qcat_scan_batch_auto / _ptrs calls of this context replayed their device work as a captured graph (a call
+ * shaped like the one before it -- same kit, read count and compacted size, no buffer reallocated -- is ONE
+ * hipGraphLaunch instead of ~45 kernel launches on twelve streams; QCAT_HIP_NO_GRAPH=1 turns that off).  Diagnostics
+ * and tests; -1: null context. */
+int64_t qcat_ctx_graph_replays(const qcat_ctx* ctx);
+
 /* Kernel timing, measured with hipEvents recorded on the context's stream around each kernel
  * phase: the AVERAGE over the qcat_scan_resident calls since the previous qcat_ctx_last_timing /
  * qcat_ctx_set_timing (a ring of 64 scans; scans need no host synchronisation between them, this

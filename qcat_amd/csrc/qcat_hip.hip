@@ -11,6 +11,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <chrono>
 #include <cstdio>
@@ -121,6 +122,7 @@ struct qcat_kit {
     KitOnDevice dev[MAX_DEVICES];
     std::vector<uint8_t> jit_code;                 // code object (gfx950) with qj_ad_<t>, qj_am_<t>, qj_bc_<t*2+s>, qj_bs_<t*2+s>
     bool jit_tpl[MAX_T] = {}, jit_grp[MAX_T * 2] = {}, jit_bsgrp[MAX_T * 2] = {};
+    uint64_t serial = 0;                           // never reused: the key of a context's captured graph (ApiGraph)
 };
 
 // launch of a run-time generated kernel (kernel id >= QCAT_JIT_BASE): the scan in progress on this
@@ -148,6 +150,8 @@ extern "C" int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {
     int rc = kit_prepare(desc, &k->hk, &err);
     if (rc) { delete k; return set_err(rc, err); }
     static_match(&k->hk);
+    static std::atomic<uint64_t> next_serial{1};
+    k->serial = next_serial.fetch_add(1);
     *out = k;
     return 0;
 }
@@ -422,6 +426,15 @@ struct qcat_ctx {
     uint8_t* hb_bases = nullptr; size_t cap_hb_bases = 0;
     uint64_t* hb_offsets = nullptr; uint32_t* hb_len = nullptr; size_t cap_hb_reads = 0;
     unsigned long long* vote_buf = nullptr;        // 2 * MAX_T counters of the kit vote
+    // the device work of a kit-auto host-buffer call as a captured graph (scan_batch_auto_impl): ~45 launches on twelve
+    // streams replayed by one hipGraphLaunch when a call has the shape of the one before it
+    struct ApiGraph {
+        hipGraphExec_t exec = nullptr;
+        uint64_t kit = 0, n_bases = 0, gen = 0; uint32_t n_reads = 0;             // what `exec` was captured for
+        uint64_t prev_kit = 0, prev_bases = 0, prev_gen = 0; uint32_t prev_reads = 0;   // the shape of the last call
+        int failures = 0;                                                         // captures that did not work out (two: never again)
+        uint64_t replays = 0;
+    } api_graph;
     // debug buffers
     int32_t* dbg_tpl = nullptr; size_t cap_dbg_tpl = 0;
     int16_t* dbg_rows = nullptr; size_t cap_dbg_rows = 0;
@@ -459,6 +472,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->api_graph.exec) (void)hipGraphExecDestroy(c->api_graph.exec);
     (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->wspec); (void)hipFree(c->win2); (void)hipFree(c->recs); (void)hipFree(c->results);
     (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows);
     (void)hipFree(c->hb_bases); (void)hipFree(c->hb_offsets); (void)hipFree(c->hb_len); (void)hipFree(c->vote_buf);
@@ -492,7 +506,7 @@ static int grow(T** p, size_t* cap, size_t need) {
     if (need <= *cap && *p) return 0;
     if (*p) { (void)hipFree(*p); *p = nullptr; }
     size_t n = std::max<size_t>(need, 1);
-    hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+    hipError_t e = q_malloc((void**)p, n * sizeof(T));
     if (e != hipSuccess) { *cap = 0; return set_err(QCAT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
     *cap = n;
     return 0;
@@ -774,6 +788,7 @@ extern "C" int qcat_ctx_fetch_counts(qcat_ctx* c, int64_t* counts, int32_t n_buc
 }
 
 extern "C" void* qcat_ctx_stream(qcat_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int64_t qcat_ctx_graph_replays(const qcat_ctx* c) { return c ? (int64_t)c->api_graph.replays : -1; }
 extern "C" void* qcat_ctx_counts_devptr(qcat_ctx* c) { return c ? c->counts : nullptr; }
 extern "C" void* qcat_ctx_results_devptr(qcat_ctx* c) { return c ? c->results : nullptr; }
 
@@ -925,13 +940,13 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
     if (total + 2 * BATCH_SLACK > c->cap_hb_bases) {
         (void)hipFree(c->hb_bases); c->hb_bases = nullptr; c->cap_hb_bases = 0;
         const size_t want = (total + 2 * BATCH_SLACK) * 5 / 4;
-        if (hipMalloc((void**)&c->hb_bases, want) != hipSuccess) return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch");
+        if (q_malloc((void**)&c->hb_bases, want) != hipSuccess) return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch");
         c->cap_hb_bases = want;
     }
     if ((size_t)n_reads + 1 > c->cap_hb_reads) {
         (void)hipFree(c->hb_offsets); (void)hipFree(c->hb_len); c->hb_offsets = nullptr; c->hb_len = nullptr; c->cap_hb_reads = 0;
         const size_t want = ((size_t)n_reads + 1) * 5 / 4;
-        if (hipMalloc((void**)&c->hb_offsets, want * 8) != hipSuccess || hipMalloc((void**)&c->hb_len, want * 4) != hipSuccess)
+        if (q_malloc((void**)&c->hb_offsets, want * 8) != hipSuccess || q_malloc((void**)&c->hb_len, want * 4) != hipSuccess)
             return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch");
         c->cap_hb_reads = want;
     }
@@ -1339,7 +1354,7 @@ static int vote_resident(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, unsign
     if (rc || !b->n_reads) return rc;
     KitOnDevice* kd = nullptr;
     if ((rc = kit_on_device(kit, c->device, &kd))) return rc;
-    if (!c->vote_buf) HIPCHK(hipMalloc((void**)&c->vote_buf, 2 * MAX_T * 8 + 16));        // (+ the chosen kit slot: scan_batch_auto_impl)
+    if (!c->vote_buf) HIPCHK(q_malloc((void**)&c->vote_buf, 2 * MAX_T * 8 + 16));        // (+ the chosen kit slot: scan_batch_auto_impl)
     unsigned long long* d = c->vote_buf;
     HIPCHK(hipMemsetAsync(d, 0, MAX_T * 8, c->stream));
     HIPCHK(hipMemsetAsync(d + MAX_T, 0xFF, MAX_T * 8, c->stream));
@@ -1391,33 +1406,77 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
     BatchGuard guard(b);
     // (a failed step drains the stream before it returns: the upload may still be reading the pinned staging)
     auto drained = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
-    // pass 1: every template of every kit against both ends (qcat/scanner_base.py:662-678)
-    if ((rc = scan_resident_impl(c, kit, b, false, 0, true))) return drained(rc);
     KitOnDevice* kd = nullptr;
     if ((rc = kit_on_device(kit, c->device, &kd))) return drained(rc);
-    if (!c->vote_buf) HIPCHK(hipMalloc((void**)&c->vote_buf, 2 * MAX_T * 8 + 16));
+    if (!c->vote_buf) HIPCHK(q_malloc((void**)&c->vote_buf, 2 * MAX_T * 8 + 16));
     unsigned long long* d = c->vote_buf;
     int32_t* chosen_dev = reinterpret_cast<int32_t*>(d + 2 * MAX_T);
-    g_fill_defer = true;
-    HIPCHK(packed_fill(d, 0, MAX_T * 8, c->stream));
-    HIPCHK(packed_fill(d + MAX_T, 0xFF, MAX_T * 8, c->stream));
-    HIPCHK(packed_fill_flush(c->stream));
-    const uint32_t blocks = std::min<uint32_t>((n_reads + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_vote, dim3(blocks), dim3(256), 0, c->stream, kd->kit, c->recs, n_reads, d, d + MAX_T);
-    hipLaunchKernelGGL(k_pick_kit, dim3(1), dim3(64), 0, c->stream, kd->kit, d, d + MAX_T, chosen_dev);
-    // pass 2: detect_barcode per read with the voted kit's templates (:714-733): the adapter alignments of the vote are still
-    // on the device -- only their merge (the kit slot read from chosen_dev), the barcode phase and the finalisation run now
-    c->packed.kit_slot_dev = chosen_dev;
-    if (getenv("QCAT_HIP_DEBUG_VOTE")) {                      // (diagnostics: the choice as the device made it, before the second pass)
-        unsigned long long dv[2 * MAX_T]; int32_t dc = -7;
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipMemcpy(dv, d, sizeof dv, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(&dc, chosen_dev, 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[qcat] vote: chosen %d (kit slots %d, templates %d):", dc, hk.n_kit_slots, hk.nt);
-        for (int t = 0; t < hk.nt; ++t) fprintf(stderr, " %llu/slot%d", dv[t], hk.tpl[t].kit_slot);
-        fprintf(stderr, "\n");
+    // the device work of the call, in stream order behind the upload
+    auto enqueue = [&]() -> int {
+        // pass 1: every template of every kit against both ends (qcat/scanner_base.py:662-678)
+        int e = scan_resident_impl(c, kit, b, false, 0, true);
+        if (e) return e;
+        g_fill_defer = true;
+        HIPCHK(packed_fill(d, 0, MAX_T * 8, c->stream));
+        HIPCHK(packed_fill(d + MAX_T, 0xFF, MAX_T * 8, c->stream));
+        HIPCHK(packed_fill_flush(c->stream));
+        const uint32_t blocks = std::min<uint32_t>((n_reads + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_vote, dim3(blocks), dim3(256), 0, c->stream, kd->kit, c->recs, n_reads, d, d + MAX_T);
+        hipLaunchKernelGGL(k_pick_kit, dim3(1), dim3(64), 0, c->stream, kd->kit, d, d + MAX_T, chosen_dev);
+        // pass 2: detect_barcode per read with the voted kit's templates (:714-733): the adapter alignments of the vote are
+        // still on the device -- only their merge (the kit slot read from chosen_dev), the barcode phase and the finalisation run now
+        c->packed.kit_slot_dev = chosen_dev;
+        if (getenv("QCAT_HIP_DEBUG_VOTE")) {                  // (diagnostics: the choice as the device made it, before the second pass)
+            unsigned long long dv[2 * MAX_T]; int32_t dc = -7;
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipMemcpy(dv, d, sizeof dv, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&dc, chosen_dev, 4, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[qcat] vote: chosen %d (kit slots %d, templates %d):", dc, hk.n_kit_slots, hk.nt);
+            for (int t = 0; t < hk.nt; ++t) fprintf(stderr, " %llu/slot%d", dv[t], hk.tpl[t].kit_slot);
+            fprintf(stderr, "\n");
+        }
+        return scan_resident_impl(c, kit, b, false, 0, false, RESUME_KIT_ON_DEVICE);
+    };
+    // A call shaped like the one before it (same kit, read count, compacted bases; nothing reallocated in between) replays
+    // that work as ONE graph launch: the launches take no arguments from the host but buffer addresses and sizes, every
+    // decision that depends on the data (kit vote, job plan, cursors) is made on the device.  The second such call captures
+    // (hipStreamBeginCapture, thread-local mode; the side streams join the capture through fork_join's events), later ones
+    // replay.  QCAT_HIP_NO_GRAPH=1: always launch kernel by kernel.  Timed contexts and the diagnostic switches (they
+    // synchronise inside the scan) never capture.
+    qcat_ctx::ApiGraph& G = c->api_graph;
+    static const char* const no_capture[] = {"QCAT_HIP_NO_GRAPH", "QCAT_HIP_DEBUG_VOTE", "QCAT_HIP_BS_TRACE", "QCAT_HIP_DEBUG_BINS", "QCAT_HIP_DEBUG_REDO"};
+    bool graph_ok = !c->timing && G.failures < 2 && b->borrowed;      // (a small batch is uploaded whole into buffers of its own)
+    for (const char* name : no_capture) if (getenv(name)) graph_ok = false;
+    const uint64_t gen_before = g_alloc_gen;
+    bool done = false;
+    if (graph_ok && G.exec && G.kit == kit->serial && G.n_reads == n_reads && G.n_bases == b->n_bases && G.gen == gen_before) {
+        c->packed.kit_slot_dev = chosen_dev;
+        g_jit = kd;
+        HIPCHK(hipGraphLaunch(G.exec, c->stream));
+        ++G.replays;
+        done = true;
+    } else if (graph_ok && G.prev_kit == kit->serial && G.prev_reads == n_reads && G.prev_bases == b->n_bases && G.prev_gen == gen_before) {
+        if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int erc = enqueue();
+            const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+            if (erc == 0 && ee == hipSuccess && graph && g_alloc_gen == gen_before &&
+                hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                G.kit = kit->serial; G.n_reads = n_reads; G.n_bases = b->n_bases; G.gen = gen_before;
+                if (hipGraphLaunch(G.exec, c->stream) == hipSuccess) done = true;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        if (!done) {                                             // (nothing of the capture ran: the plain launches below do the work)
+            (void)hipGetLastError();
+            if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+            ++G.failures;
+            g_fill_defer = false; g_fill.n = 0;
+        }
     }
-    if ((rc = scan_resident_impl(c, kit, b, false, 0, false, RESUME_KIT_ON_DEVICE))) return drained(rc);
+    if (!done && (rc = enqueue())) return drained(rc);
+    G.prev_kit = kit->serial; G.prev_reads = n_reads; G.prev_bases = b->n_bases; G.prev_gen = g_alloc_gen;
     unsigned long long hv[MAX_T], hf[MAX_T];
     int32_t chosen = -1;
     std::vector<int64_t> tmp(counts ? (size_t)hk.n_buckets : 0);

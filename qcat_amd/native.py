@@ -292,6 +292,7 @@ class HipLibrary(object):
             "qcat_kit_attach_code_quads": (C.c_int, [vp, C.c_char_p, C.c_uint64, C.POINTER(i32), C.POINTER(i32),
                                                     C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
             "qcat_ctx_stream": (vp, [vp]),
+            "qcat_ctx_graph_replays": (C.c_int64, [vp]),
             "qcat_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
             "qcat_ctx_destroy": (None, [vp]),
             "qcat_scan_batch": (C.c_int, [vp, vp, vp, vp, u32, vp, vp]),

@@ -179,3 +179,41 @@ def test_reads_handed_over_as_pointers_give_the_same_dicts(monkeypatch):
     _same(det.detect_barcode_batch(reads[:100], quals[:100], cfg), _two_pass(det, reads[:100], cfg)[1])
     empty = det.detect_barcode_batch(["", ""], [None, None], cfg)
     assert all(r["barcode"] is None for r in empty)
+
+
+def test_calls_of_one_shape_replay_a_captured_graph(monkeypatch):
+    """Round 4: the second kit-auto call of a shape captures its device work (two adapter / barcode passes, vote, kit choice:
+    ~45 launches on twelve streams) and later calls replay it with one hipGraphLaunch.  Everything that depends on the data is
+    decided on the device, so a replay over OTHER reads -- another majority kit -- must still give the two-pass records."""
+    det = scanner.factory()
+    cfg = config.qcatConfig()
+    lib = native.HipLibrary.get().lib
+    ctx = det._context()
+    batches = [_mixed_batch(det, m, 4000, s) for m, s in (("PBC096", 11), ("RBK004", 12), ("NBD104/NBD114", 13))]
+    want = [_two_pass(det, r, cfg) for r in batches]
+
+    def run(reads):
+        return det.detect_barcode_batch(reads, [None] * len(reads), cfg), None
+
+    def compacted(reads):
+        return sum(min(len(r), 300) for r in reads)
+
+    assert len({(len(r), compacted(r)) for r in batches}) == 1, "the three batches must have one shape"
+    before = lib.qcat_ctx_graph_replays(ctx.handle)
+    order = [0, 0, 1, 2, 0, 1]                                  # plain, capture, then replays over other reads
+    for i in order:
+        got, _ = run(batches[i])
+        _same(got, want[i][1])
+    assert lib.qcat_ctx_graph_replays(ctx.handle) - before >= 3
+    # another read count: launched kernel by kernel again (and captured anew on its second call)
+    mid = lib.qcat_ctx_graph_replays(ctx.handle)
+    short = batches[0][:3000]
+    _same(run(short)[0], _two_pass(det, short, cfg)[1])
+    assert lib.qcat_ctx_graph_replays(ctx.handle) == mid
+    # ... and back: the graph of the old shape is gone (its buffers may have moved), two calls later it replays again
+    for i in (1, 1, 2):
+        _same(run(batches[i])[0], want[i][1])
+    monkeypatch.setenv("QCAT_HIP_NO_GRAPH", "1")
+    off = lib.qcat_ctx_graph_replays(ctx.handle)
+    _same(run(batches[2])[0], want[2][1])
+    assert lib.qcat_ctx_graph_replays(ctx.handle) == off

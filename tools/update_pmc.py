@@ -17,12 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernel-name fragments -> the timing mark their launches are enclosed by (packed_host.inc / qcat_hip.hip)
 MARKS = [
-    ("k_pack_windows", "k_pack_windows"),
+    ("k_pack_windows", "k_pack_windows"), ("k_expand_special", "k_pack_windows"), ("k_fill_multi", "k_pack_windows"),
+    ("k_mid_windows", "k_middle_packed"), ("k_adapter_middle", "k_middle_packed"), ("k_middle", "k_middle_packed"), ("k_mid_", "k_middle_packed"),
     ("k_adapter_finish", "k_job_sort"),                 # (launched after the adapter phase's mark: its time is in the next one)
-    ("k_abs_", "k_adapter_static"), ("k_adapter_bs", "k_adapter_static"), ("k_adapter_ms", "k_adapter_static"),
+    ("k_abs_", "k_adapter_static"), ("k_adapter_bs", "k_adapter_static"), ("k_adapter_ms", "k_adapter_static"), ("k_adapter_mw", "k_adapter_static"),
     ("k_adapter_fused2", "k_adapter_static"), ("k_adapter_static", "k_adapter_static"),
     ("k_adapter_packed", "k_adapter_packed"),
-    ("k_job_", "k_job_sort"),
+    ("k_job_", "k_job_sort"), ("k_bs_plan", "k_job_sort"),
     ("k_bs_", "k_barcode_bitslice"),
     ("k_barcode_static", "k_barcode_static"), ("k_barcode_packed", "k_barcode_packed"),
     ("k_barcode_select", "k_barcode_select"), ("k_barcode_redo", "k_barcode_select"),
@@ -92,7 +93,7 @@ def main():
         # scans in the profiled run = dispatches of k_finalize (one per scan)
         n_scans = max([len(v) for k, v in insts.items() if "k_finalize" in k] or [1])
         marks = defaultdict(lambda: {"insts_valu": 0.0, "kernels": []})
-        abs_ran = any("k_adapter_bs" in k or "k_adapter_ms" in k for k in insts)          # the adapter phase's mark says which kernels took the batch
+        abs_ran = any("k_adapter_bs" in k or "k_adapter_ms" in k or "k_adapter_mw" in k for k in insts)          # the adapter phase's mark says which kernels took the batch
         for kname, vals in insts.items():
             m = mark_of(kname)
             if m is None:
