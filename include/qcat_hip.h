@@ -279,6 +279,17 @@ int  qcat_scan_batch_auto_ptrs(qcat_ctx* ctx, const qcat_kit* kit,
                                qcat_result* out, int64_t* counts, int32_t* chosen_kit_slot,
                                int64_t* votes, int64_t* first_read);
 
+/* Several consecutive kit-auto batches in ONE call (round 4; replaces: the driver's loop over detect_barcode_batch,
+ * qcat/cli.py:500-513 -- the reference votes per batch of 4000 reads in file order): reads [q * batch_reads,
+ * (q + 1) * batch_reads) are batch q; every batch votes for its own kit (scanner_base.py:662-678) and its reads are scanned
+ * with that kit's templates (:714-733) -- one adapter pass over all reads, votes counted and decided per batch on the
+ * device.  chosen_kit_slots: one entry per batch (ceil(n_reads / batch_reads), at most 65535).  Results are identical to
+ * one qcat_scan_batch_auto_ptrs call per batch; a 4000-read batch alone keeps the device busy for a fraction of its
+ * 0.9 ms call. */
+int  qcat_scan_batches_auto_ptrs(qcat_ctx* ctx, const qcat_kit* kit, const uint8_t* const* reads, const uint64_t* lengths,
+                                 uint32_t n_reads, uint32_t batch_reads, qcat_result* out, int64_t* counts,
+                                 int32_t* chosen_kit_slots);
+
 /* replaces: BarcodeScanner.scan(read_sequence, ...) on sequences of ANY length (qcat/scanner_base.py:466-477;
  * scanner_epi2me.py:33-144, scanner_dual.py:35-146) -- the form scan_middle uses on read interiors
  * (scanner_base.py:479-519) and qcat/eval_full.py:199-203 on whole reads.  Every sequence is one window: all

@@ -410,6 +410,7 @@ struct qcat_ctx {
     uint8_t* pin_bases = nullptr; size_t cap_pin_bases = 0;
     uint64_t* pin_offsets = nullptr; uint32_t* pin_len = nullptr; size_t cap_pin_reads = 0;
     HostPipeline* pipe = nullptr;                  // chunked host-buffer scans (host_pipeline.inc), created on first use
+    std::vector<qcat_ctx*> helpers;                // contexts of the kit-auto file loop's other workers (fastq_host.inc), created on first use
     PackedScratch packed;
     // packed --detect-middle (kernels_middle.inc): M-end sort tables and per-slot arrays
     MidTables* mid_tables = nullptr;
@@ -425,13 +426,14 @@ struct qcat_ctx {
     // reused -- a 4000-read batch of the reference driver's call shape spent a third of its call in six hipMalloc / hipFree
     uint8_t* hb_bases = nullptr; size_t cap_hb_bases = 0;
     uint64_t* hb_offsets = nullptr; uint32_t* hb_len = nullptr; size_t cap_hb_reads = 0;
-    unsigned long long* vote_buf = nullptr;        // 2 * MAX_T counters of the kit vote
+    unsigned long long* vote_buf = nullptr;        // per batch of a kit vote: MAX_T counters, MAX_T first voters, then one chosen slot each
+    size_t cap_vote_batches = 0;
     // the device work of a kit-auto host-buffer call as a captured graph (scan_batch_auto_impl): ~45 launches on twelve
     // streams replayed by one hipGraphLaunch when a call has the shape of the one before it
     struct ApiGraph {
         hipGraphExec_t exec = nullptr;
-        uint64_t kit = 0, n_bases = 0, gen = 0; uint32_t n_reads = 0;             // what `exec` was captured for
-        uint64_t prev_kit = 0, prev_bases = 0, prev_gen = 0; uint32_t prev_reads = 0;   // the shape of the last call
+        uint64_t kit = 0, n_bases = 0, gen = 0; uint32_t n_reads = 0, batch_reads = 0;             // what `exec` was captured for
+        uint64_t prev_kit = 0, prev_bases = 0, prev_gen = 0; uint32_t prev_reads = 0, prev_batch = 0;   // the shape of the last call
         int failures = 0;                                                         // captures that did not work out (two: never again)
         uint64_t replays = 0;
     } api_graph;
@@ -470,6 +472,8 @@ extern "C" int qcat_ctx_create(int device, qcat_ctx** out) {
 
 extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     if (!c) return;
+    for (qcat_ctx* h : c->helpers) qcat_ctx_destroy(h);
+    c->helpers.clear();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->api_graph.exec) (void)hipGraphExecDestroy(c->api_graph.exec);
@@ -1347,6 +1351,15 @@ extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
     return rc;
 }
 
+// the vote's device buffer for nb batches: votes [nb][MAX_T], first voters [nb][MAX_T], chosen slots [nb]
+static int vote_buffer(qcat_ctx* c, size_t nb) {
+    if (c->vote_buf && nb <= c->cap_vote_batches) return 0;
+    if (c->vote_buf) { (void)hipFree(c->vote_buf); c->vote_buf = nullptr; c->cap_vote_batches = 0; }
+    HIPCHK(q_malloc((void**)&c->vote_buf, nb * (2 * MAX_T * 8 + 4) + 16));
+    c->cap_vote_batches = nb;
+    return 0;
+}
+
 // adapter-only pass over a resident batch + k_vote: per-template votes / first voting read (host arrays of MAX_T)
 static int vote_resident(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, unsigned long long* hv, unsigned long long* hf) {
     for (int t = 0; t < MAX_T; ++t) { hv[t] = 0; hf[t] = ~0ull; }
@@ -1354,7 +1367,7 @@ static int vote_resident(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, unsign
     if (rc || !b->n_reads) return rc;
     KitOnDevice* kd = nullptr;
     if ((rc = kit_on_device(kit, c->device, &kd))) return rc;
-    if (!c->vote_buf) HIPCHK(q_malloc((void**)&c->vote_buf, 2 * MAX_T * 8 + 16));        // (+ the chosen kit slot: scan_batch_auto_impl)
+    if ((rc = vote_buffer(c, 1))) return rc;
     unsigned long long* d = c->vote_buf;
     HIPCHK(hipMemsetAsync(d, 0, MAX_T * 8, c->stream));
     HIPCHK(hipMemsetAsync(d + MAX_T, 0xFF, MAX_T * 8, c->stream));
@@ -1393,13 +1406,19 @@ extern "C" int qcat_detect_kit(qcat_ctx* c, const qcat_kit* ckit, const uint8_t*
 static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t* bases, const uint64_t* offsets,
                                 const uint8_t* const* ptrs, const uint64_t* lens,
                                 uint32_t n_reads, qcat_result* out, int64_t* counts, int32_t* chosen_kit_slot,
-                                int64_t* votes, int64_t* first_read) {
+                                int64_t* votes, int64_t* first_read, uint32_t batch_reads = 0) {
+    // batch_reads > 0 (round 4, the kit-auto file loop): the reads are consecutive batches of that many reads, each votes for
+    // a kit of its own (qcat/cli.py:500 calls detect_barcode_batch per batch) -- one adapter pass over all of them, the votes
+    // counted and decided per batch (k_vote / k_pick_kit with a batch dimension), the second pass takes every read's kit slot
+    // from its batch (k_adapter_finish: slot_span); chosen_kit_slot then has one entry per batch, votes / first_read are unused
     if (!c || !ckit || (n_reads && !offsets && !ptrs) || !out || !chosen_kit_slot) return set_err(QCAT_ERR_ARG, "qcat_scan_batch_auto: null argument");
     qcat_kit* kit = const_cast<qcat_kit*>(ckit);
     const DevKit& hk = kit->hk.dk;
     if (hk.ends != QCAT_ENDS_BOTH) return set_err(QCAT_ERR_ARG, "qcat_scan_batch_auto needs a kit created with QCAT_ENDS_BOTH");
-    *chosen_kit_slot = -1;
+    const uint32_t nb = batch_reads ? (n_reads + batch_reads - 1) / batch_reads : 1u;
+    for (uint32_t q = 0; q < std::max(1u, nb); ++q) chosen_kit_slot[q] = -1;
     if (!n_reads) return 0;                                     // (an empty batch: nobody votes, nothing to scan)
+    if (batch_reads && (votes || first_read)) return set_err(QCAT_ERR_ARG, "qcat_scan_batches_auto: the per-template votes are reported for one batch only");
     qcat_batch* b = nullptr;
     int rc = batch_upload_windows(c, kit, bases, offsets, n_reads, &b, ptrs, lens);
     if (rc) return rc;
@@ -1408,24 +1427,27 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
     auto drained = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
     KitOnDevice* kd = nullptr;
     if ((rc = kit_on_device(kit, c->device, &kd))) return drained(rc);
-    if (!c->vote_buf) HIPCHK(q_malloc((void**)&c->vote_buf, 2 * MAX_T * 8 + 16));
+    if ((rc = vote_buffer(c, nb))) return drained(rc);
     unsigned long long* d = c->vote_buf;
-    int32_t* chosen_dev = reinterpret_cast<int32_t*>(d + 2 * MAX_T);
+    unsigned long long* d_first = d + (size_t)nb * MAX_T;
+    int32_t* chosen_dev = reinterpret_cast<int32_t*>(d + 2 * (size_t)nb * MAX_T);
+    const uint32_t slot_span = batch_reads ? batch_reads * 2u : 0u;        // read ends per batch (both ends: checked above)
     // the device work of the call, in stream order behind the upload
     auto enqueue = [&]() -> int {
         // pass 1: every template of every kit against both ends (qcat/scanner_base.py:662-678)
         int e = scan_resident_impl(c, kit, b, false, 0, true);
         if (e) return e;
         g_fill_defer = true;
-        HIPCHK(packed_fill(d, 0, MAX_T * 8, c->stream));
-        HIPCHK(packed_fill(d + MAX_T, 0xFF, MAX_T * 8, c->stream));
+        HIPCHK(packed_fill(d, 0, (size_t)nb * MAX_T * 8, c->stream));
+        HIPCHK(packed_fill(d_first, 0xFF, (size_t)nb * MAX_T * 8, c->stream));
         HIPCHK(packed_fill_flush(c->stream));
-        const uint32_t blocks = std::min<uint32_t>((n_reads + 255) / 256, 1024);
-        hipLaunchKernelGGL(k_vote, dim3(blocks), dim3(256), 0, c->stream, kd->kit, c->recs, n_reads, d, d + MAX_T);
-        hipLaunchKernelGGL(k_pick_kit, dim3(1), dim3(64), 0, c->stream, kd->kit, d, d + MAX_T, chosen_dev);
+        const uint32_t per = batch_reads ? batch_reads : n_reads;
+        const uint32_t blocks = std::min<uint32_t>((per + 255) / 256, batch_reads ? 64 : 1024);
+        hipLaunchKernelGGL(k_vote, dim3(blocks, nb), dim3(256), 0, c->stream, kd->kit, c->recs, n_reads, d, d_first, batch_reads);
+        hipLaunchKernelGGL(k_pick_kit, dim3(nb), dim3(64), 0, c->stream, kd->kit, d, d_first, chosen_dev);
         // pass 2: detect_barcode per read with the voted kit's templates (:714-733): the adapter alignments of the vote are
         // still on the device -- only their merge (the kit slot read from chosen_dev), the barcode phase and the finalisation run now
-        c->packed.kit_slot_dev = chosen_dev;
+        c->packed.kit_slot_dev = chosen_dev; c->packed.kit_slot_span = slot_span;
         if (getenv("QCAT_HIP_DEBUG_VOTE")) {                  // (diagnostics: the choice as the device made it, before the second pass)
             unsigned long long dv[2 * MAX_T]; int32_t dc = -7;
             (void)hipStreamSynchronize(c->stream);
@@ -1449,13 +1471,13 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
     for (const char* name : no_capture) if (getenv(name)) graph_ok = false;
     const uint64_t gen_before = g_alloc_gen;
     bool done = false;
-    if (graph_ok && G.exec && G.kit == kit->serial && G.n_reads == n_reads && G.n_bases == b->n_bases && G.gen == gen_before) {
-        c->packed.kit_slot_dev = chosen_dev;
+    if (graph_ok && G.exec && G.kit == kit->serial && G.n_reads == n_reads && G.n_bases == b->n_bases && G.gen == gen_before && G.batch_reads == batch_reads) {
+        c->packed.kit_slot_dev = chosen_dev; c->packed.kit_slot_span = slot_span;
         g_jit = kd;
         HIPCHK(hipGraphLaunch(G.exec, c->stream));
         ++G.replays;
         done = true;
-    } else if (graph_ok && G.prev_kit == kit->serial && G.prev_reads == n_reads && G.prev_bases == b->n_bases && G.prev_gen == gen_before) {
+    } else if (graph_ok && G.prev_kit == kit->serial && G.prev_reads == n_reads && G.prev_bases == b->n_bases && G.prev_gen == gen_before && G.prev_batch == batch_reads) {
         if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -1463,7 +1485,7 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
             const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
             if (erc == 0 && ee == hipSuccess && graph && g_alloc_gen == gen_before &&
                 hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                G.kit = kit->serial; G.n_reads = n_reads; G.n_bases = b->n_bases; G.gen = gen_before;
+                G.kit = kit->serial; G.n_reads = n_reads; G.n_bases = b->n_bases; G.gen = gen_before; G.batch_reads = batch_reads;
                 if (hipGraphLaunch(G.exec, c->stream) == hipSuccess) done = true;
             }
             if (graph) (void)hipGraphDestroy(graph);
@@ -1476,22 +1498,26 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
         }
     }
     if (!done && (rc = enqueue())) return drained(rc);
-    G.prev_kit = kit->serial; G.prev_reads = n_reads; G.prev_bases = b->n_bases; G.prev_gen = g_alloc_gen;
+    G.prev_kit = kit->serial; G.prev_reads = n_reads; G.prev_bases = b->n_bases; G.prev_gen = g_alloc_gen; G.prev_batch = batch_reads;
     unsigned long long hv[MAX_T], hf[MAX_T];
-    int32_t chosen = -1;
+    std::vector<int32_t> chosen((size_t)nb, -1);
     std::vector<int64_t> tmp(counts ? (size_t)hk.n_buckets : 0);
-    HIPCHK(hipMemcpyAsync(hv, d, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(hf, d + MAX_T, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&chosen, chosen_dev, 4, hipMemcpyDeviceToHost, c->stream));
+    if (!batch_reads) {
+        HIPCHK(hipMemcpyAsync(hv, d, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(hf, d_first, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(chosen.data(), chosen_dev, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(out, c->results, (size_t)n_reads * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream));
     if (counts) HIPCHK(hipMemcpyAsync(tmp.data(), c->counts, (size_t)hk.n_buckets * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int t = 0; t < hk.nt; ++t) {
-        if (votes) votes[t] += (int64_t)hv[t];
-        if (first_read) first_read[t] = hf[t] == ~0ull ? (int64_t)n_reads : (int64_t)hf[t];
-    }
-    *chosen_kit_slot = chosen;
-    if (chosen < 0) return set_err(QCAT_ERR_DEVICE, "qcat_scan_batch_auto: no read voted");
+    if (!batch_reads)
+        for (int t = 0; t < hk.nt; ++t) {
+            if (votes) votes[t] += (int64_t)hv[t];
+            if (first_read) first_read[t] = hf[t] == ~0ull ? (int64_t)n_reads : (int64_t)hf[t];
+        }
+    bool all_voted = true;
+    for (uint32_t q = 0; q < nb; ++q) { chosen_kit_slot[q] = chosen[q]; all_voted = all_voted && chosen[q] >= 0; }
+    if (!all_voted) return set_err(QCAT_ERR_DEVICE, "qcat_scan_batch_auto: no read voted");
     if (counts) for (size_t i = 0; i < tmp.size(); ++i) counts[i] += tmp[i];
     return 0;
 }
@@ -1507,6 +1533,16 @@ extern "C" int qcat_scan_batch_auto_ptrs(qcat_ctx* c, const qcat_kit* ckit, cons
                                          int64_t* votes, int64_t* first_read) {
     if (n_reads && (!reads || !lengths)) return set_err(QCAT_ERR_ARG, "qcat_scan_batch_auto_ptrs: null argument");
     return scan_batch_auto_impl(c, ckit, nullptr, nullptr, reads, lengths, n_reads, out, counts, chosen_kit_slot, votes, first_read);
+}
+
+extern "C" int qcat_scan_batches_auto_ptrs(qcat_ctx* c, const qcat_kit* ckit, const uint8_t* const* reads, const uint64_t* lengths,
+                                           uint32_t n_reads, uint32_t batch_reads, qcat_result* out, int64_t* counts, int32_t* chosen_kit_slots) {
+    if (n_reads && (!reads || !lengths)) return set_err(QCAT_ERR_ARG, "qcat_scan_batches_auto_ptrs: null argument");
+    if (!batch_reads) return set_err(QCAT_ERR_ARG, "qcat_scan_batches_auto_ptrs: batch_reads must be positive");
+    if (batch_reads >= n_reads)                                 // one batch: the plain call (small batches upload whole reads)
+        return scan_batch_auto_impl(c, ckit, nullptr, nullptr, reads, lengths, n_reads, out, counts, chosen_kit_slots, nullptr, nullptr);
+    if ((uint64_t)(n_reads + batch_reads - 1) / batch_reads > 65535u) return set_err(QCAT_ERR_ARG, "qcat_scan_batches_auto_ptrs: more than 65535 batches in one call");
+    return scan_batch_auto_impl(c, ckit, nullptr, nullptr, reads, lengths, n_reads, out, counts, chosen_kit_slots, nullptr, nullptr, batch_reads);
 }
 
 extern "C" int qcat_scan_batch(qcat_ctx* c, const qcat_kit* kit,

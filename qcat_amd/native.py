@@ -301,6 +301,7 @@ class HipLibrary(object):
             "qcat_scan_sequences": (C.c_int, [vp, vp, vp, vp, u32, vp]),
             "qcat_scan_batch_auto": (C.c_int, [vp, vp, vp, vp, u32, vp, vp, C.POINTER(i32), vp, vp]),
             "qcat_scan_batch_auto_ptrs": (C.c_int, [vp, vp, C.c_char_p, C.c_char_p, u32, vp, vp, C.POINTER(i32), vp, vp]),
+            "qcat_scan_batches_auto_ptrs": (C.c_int, [vp, vp, C.c_char_p, C.c_char_p, u32, u32, vp, vp, vp]),
             "qcat_batch_upload": (C.c_int, [vp, vp, vp, u32, C.POINTER(vp)]),
             "qcat_batch_synthesize": (C.c_int, [vp, vp, C.POINTER(SynthParams), C.POINTER(vp)]),
             "qcat_batch_destroy": (None, [vp]),
@@ -528,6 +529,16 @@ class NativeContext(object):
             return None
         self.hip.check(rc)
         return out, int(slot.value)
+
+    def scan_batches_auto_views(self, kit, views, n, batch_reads):
+        """qcat_scan_batches_auto_ptrs: consecutive kit-auto batches of ``batch_reads`` reads in one call;
+        (records, voted kit slot per batch)."""
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        nb = max(1, (n + batch_reads - 1) // batch_reads)
+        slots = np.full(nb, -1, dtype=np.int32)
+        self.hip.check(self.hip.lib.qcat_scan_batches_auto_ptrs(self.handle, kit.handle, views[0], views[1], n, batch_reads,
+                                                                out.ctypes.data, None, slots.ctypes.data))
+        return out, slots
 
     def scan_sequences(self, kit, bases, offsets):
         """scan() of whole sequences of any length (qcat_scan_sequences): one record per sequence."""

@@ -217,3 +217,29 @@ def test_calls_of_one_shape_replay_a_captured_graph(monkeypatch):
     off = lib.qcat_ctx_graph_replays(ctx.handle)
     _same(run(batches[2])[0], want[2][1])
     assert lib.qcat_ctx_graph_replays(ctx.handle) == off
+
+
+def test_several_batches_in_one_call_vote_one_by_one():
+    """Round 4 (the kit-auto file loop): qcat_scan_batches_auto_ptrs scans consecutive batches in one call, each with the kit
+    its own reads voted for -- the records and the per-batch kit slots must equal one qcat_scan_batch_auto_ptrs call per batch."""
+    if native._pyglue is None:
+        pytest.skip("the optional C helper is not built")
+    det = scanner.factory()
+    cfg = config.qcatConfig()
+    ctx = det._context()
+    kit = det._native_kit(det.layouts, cfg, native.ENDS_BOTH)
+    reads = []
+    for m, s in (("PBC096", 21), ("RBK004", 22), ("NBD104/NBD114", 23), ("RAB204/RAB214", 24), ("PBC096", 25)):
+        reads += _mixed_batch(det, m, 1500, s)[:1500]
+    reads += _mixed_batch(det, "RBK004", 700, 26)[:611]           # a short last batch
+    views = native.read_views(reads)
+    recs, slots = ctx.scan_batches_auto_views(kit, views, len(reads), 1500)
+    assert len(slots) == 6 and len(set(slots.tolist())) >= 4
+    for q in range(6):
+        part = reads[q * 1500:(q + 1) * 1500]
+        one, slot = ctx.scan_auto_views(kit, native.read_views(part), len(part))
+        assert slot == slots[q]
+        assert np.array_equal(one, recs[q * 1500:q * 1500 + len(part)]), q
+    # one batch only (batch_reads >= n): the plain call
+    recs1, slots1 = ctx.scan_batches_auto_views(kit, native.read_views(reads[:1500]), 1500, 4000)
+    assert len(slots1) == 1 and slots1[0] == slots[0] and np.array_equal(recs1, recs[:1500])

@@ -130,3 +130,60 @@ def test_native_writers_to_a_file_a_pipe_and_an_append_descriptor(tmp_path):
     assert (tmp_path / "direct.tsv").read_bytes() == want
     assert piped == want
     assert (tmp_path / "append.tsv").read_bytes() == b"a line that was there\n" + want
+
+
+def test_kit_auto_file_loop_on_several_contexts(tmp_path, monkeypatch):
+    """Round 4: the kit-auto file loop (one vote per batch of 4000 reads, qcat/cli.py:500) hands its batches to up to four
+    workers with a context each.  A file of mixed kits -- the vote changes from batch to batch -- must give the same TSV and
+    the same records with one worker, with four, and through the Python loop over detect_barcode_batch."""
+    import numpy as np
+    import synth
+    from qcat_amd import native, scanner
+    det = scanner.factory()
+    lays = det.layouts
+    by_kit = {}
+    for i, l in enumerate(lays):
+        by_kit.setdefault(l.kit, []).append(i)
+    reads = []
+    for b, kit in enumerate(["PBC096", "RBK004", "NBD104/NBD114", "PBC096", "RAB204/RAB214", "PBK004/LWB001", "PBC096"]):
+        idx = by_kit[kit]
+        other = by_kit["RBK004" if kit != "RBK004" else "PBC096"]
+        part = synth.synth_batch(700, 100 + b, lays, idx[-1], idx[0] if len(idx) > 1 else -1, error_rate=0.08)
+        part += synth.synth_batch(300, 200 + b, lays, other[-1], other[0] if len(other) > 1 else -1, error_rate=0.08)
+        reads += part                                           # batches of 1000: 70 % of one kit, 30 % of another
+    reads += synth.synth_batch(317, 999, lays, by_kit["PBC096"][-1], by_kit["PBC096"][0], error_rate=0.08)   # a short last batch
+    fq = str(tmp_path / "mixed.fastq")
+    with open(fq, "w") as fh:
+        for i, r in enumerate(reads):
+            fh.write("@r%d ch=%d\n%s\n+\n%s\n" % (i, i % 512, r, "I" * len(r)))
+    cfg = config.qcatConfig()
+    kit = det._native_kit(lays, cfg, native.ENDS_BOTH)
+
+    def run(workers):
+        monkeypatch.setenv("QCAT_HIP_AUTO_WORKERS", str(workers))
+        f = native.FastqFile(fq)
+        out = str(tmp_path / ("w%d.tsv" % workers))
+        with open(out, "wb") as fh:
+            recs, skipped, st = f.demux(det._context(), kit, lays, False, batch_size=1000, kit_auto=True, trim=True,
+                                        min_read_length=100, tsv_fd=fh.fileno())
+        f.close()
+        with open(out, "rb") as fh:
+            return recs, skipped, fh.read()
+
+    r1, s1, t1 = run(1)
+    r4, s4, t4 = run(4)
+    assert t1 == t4 and np.array_equal(r1, r4) and np.array_equal(s1, s4)
+    assert t1.count(b"\n") == len(reads)
+    # the Python loop of the reference's call shape, batch by batch
+    want = []
+    for first in range(0, len(reads), 1000):
+        chunk = reads[first:first + 1000]
+        want += det.detect_barcode_batch(chunk, [None] * len(chunk), cfg)
+    got = det._records_to_dicts(r4, lays)
+    kits_called = set()
+    for g, w in zip(got, want):
+        assert g["barcode"] is w["barcode"] and g["adapter"] is w["adapter"] and g["exit_status"] == w["exit_status"]
+        assert (g["trim5p"], g["trim3p"]) == (w["trim5p"], w["trim3p"])
+        if w["adapter"] is not None:
+            kits_called.add(w["adapter"].kit)
+    assert len(kits_called) >= 4                              # the vote did change between batches

@@ -123,6 +123,15 @@ for label, out, tsv in (("tsv", None, True), ("per_barcode_fastq", os.path.join(
     fq.close()
     sink.close()
     res["native_" + label]["split_s"] = {k: round(st[k], 4) for k in ("parse_s", "scan_s", "write_s", "total_s")}
+# ---- the driver's DEFAULT: kit auto, one vote per batch of 4000 reads (qcat/cli.py:500) -- every batch a call of its own;
+#      round 4: chunks of 64 batches per call (qcat_scan_batches_auto_ptrs: one vote per batch on the device), reads as pointers into the mapping
+for label, chunk in (("one_call_per_batch", "1"), ("default", None)):          # (round 3's loop; chunks of 64 batches per call)
+    if chunk:
+        os.environ["QCAT_HIP_AUTO_CHUNK"] = chunk
+    else:
+        os.environ.pop("QCAT_HIP_AUTO_CHUNK", None)
+    dt = min(run(big, "auto", None, True, True, tsv_file=os.path.join(tmp, "big_auto.tsv"))[0] for _ in range(2))
+    res["native_tsv_kit_auto_" + label] = {"reads_per_s": round(n / dt, 1), "seconds": round(dt, 3)}
 res["note"] = ("host-bound: the file is split at parse_gb_per_s on the host threads, the scan reads heads and tails of the reads in "
                "place, the writers format on the host threads beside the scan (total_s = the demux call, seconds = the whole driver run incl. context set-up); per-barcode FASTQ output rewrites every byte of the input")
 print(json.dumps(res))
