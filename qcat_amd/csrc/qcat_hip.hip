@@ -576,8 +576,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     // them -- run on the bit-sliced barcode kernels (QCAT_HIP_MIDDLE_NO_BITSLICE=1: binary16 kernels as before)
     const bool mid_bs = getenv("QCAT_HIP_MIDDLE_NO_BITSLICE") == nullptr;
     if (mid_bs) {
-        HIPCHK(hipMemsetAsync(c->mid_wspec, 0, slots + 4, st));
-        const uint64_t wthreads = (uint64_t)slots * WIN2_WORDS;
+        const uint64_t wthreads = (uint64_t)slots * 16;           // (sixteen lanes per slot; every slot's flag byte is stored, no fill)
         hipLaunchKernelGGL(k_mid_windows, dim3((uint32_t)((wthreads + 255) / 256)), dim3(256), 0, st, b->bases, b->offsets, hk.max_align,
                            c->mid_sorted, (uint32_t)slots, c->mid_win2, c->mid_wspec);
     }
