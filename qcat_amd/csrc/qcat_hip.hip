@@ -598,11 +598,11 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
                            c->mid_bests, hk.nt, c->mid_recs, sc->jt, (const int32_t*)c->mid_fallback, -1, (const uint8_t*)sc->wspec, sc->jobinfo, (int2*)nullptr, (uint32_t*)nullptr);
     }
     const int nsets = hk.mode == QCAT_MODE_DUAL ? 2 : 1;
-    rc = packed_barcode(st, kp, hk, (uint32_t)slots, c->mid_recs, sc, [&](uint32_t max_tiles, const BsPlan*) {
+    rc = packed_barcode(st, kp, hk, (uint32_t)slots, c->mid_recs, sc, [&](uint32_t max_tiles, const BsPlan* taken, hipStream_t gq) {
         const uint64_t gthreads = (uint64_t)max_tiles * 64 * (WIN_STRIDE / 16);
-        hipLaunchKernelGGL(k_mid_gather, dim3((uint32_t)((gthreads + 255) / 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_mid_gather, dim3((uint32_t)((gthreads + 255) / 256)), dim3(256), 0, gq,
                            b->bases, b->offsets, hk.max_align, c->mid_sorted, c->mid_recs, sc->sorted, sc->jt, nsets,
-                           sc->tilebuf, sc->tmeta);
+                           sc->tilebuf, sc->tmeta, taken);
     }, (int16_t*)nullptr, 0u, [](const char*) {});
     if (!rc) rc = jit_take_error();
     if (rc) return set_err(rc, packed_last_error());
@@ -736,9 +736,11 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         mark(c, "k_scan_generic");
     }
     if (!adapter_only) {
-        // every block zeroes and flushes an LDS histogram of n_buckets entries: fewer, fatter blocks
-        // when the bucket vector is long (dual kits)
-        uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, hk.n_buckets > 2048 ? 512 : 4096);
+        // every block zeroes and flushes an LDS histogram of n_buckets entries with global atomics on the same few counters:
+        // fewer, fatter blocks -- 1024 (measured, tools/r04_fin.sh: config 2 0.059 -> 0.028 ms against 4096 blocks, config 3
+        // 0.235 -> 0.207 ms), 512 when the bucket vector is long (dual kits: 0.052 against 0.072 ms)
+        const char* fb_env = getenv("QCAT_HIP_FIN_BLOCKS");                          // (A/B runs)
+        uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, fb_env ? (uint64_t)std::max(1, atoi(fb_env)) : (hk.n_buckets > 2048 ? 512 : 1024));
         const bool middle = hk.scan_middle != 0;
         hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), fin_lds_bytes(hk.n_buckets, !middle), c->stream,
                            kp, c->recs, b->offsets, b->true_len, n, c->results, middle ? nullptr : c->counts,
@@ -1490,6 +1492,9 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
             if (graph) (void)hipGraphDestroy(graph);
         }
         if (!done) {                                             // (nothing of the capture ran: the plain launches below do the work)
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(c->stream);
+            packed_streams_reset(&c->packed);                    // (fresh side streams: the old ones may still think they capture)
             (void)hipGetLastError();
             if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
             ++G.failures;
