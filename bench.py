@@ -553,15 +553,19 @@ def api4000(a, hip, lib):
     native.pack_reads = timed("pack_reads_s", orig_pack)
     native.read_views = timed("pack_reads_s", orig_views)     # (the str objects' buffers handed over as they are: csrc/pyglue.c)
     det._records_to_dicts = timed("dicts_s", orig_dicts)
-    called = 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         for b, q in zip(batches, quals):
             res = det.detect_barcode_batch(b, q, cfg)
-            called += sum(1 for r in res if r["barcode"] is not None)
     elapsed = time.perf_counter() - t0
     ctx.scan_auto, native.pack_reads, det._records_to_dicts = orig_scan_auto, orig_pack, orig_dicts
     native.read_views, ctx.scan_auto_views = orig_views, orig_scan_views
+    # the sanity figure `called_fraction` comes from one more pass outside the timed region (counting 4000 dicts in Python is
+    # 0.25 ms per call: the bench's own bookkeeping, not the call's)
+    called = 0
+    for b, q in zip(batches, quals):
+        called += sum(1 for r in det.detect_barcode_batch(b, q, cfg) if r["barcode"] is not None)
+    called *= a.steps
     n_calls = a.steps * len(batches)
     total = a.steps * len(reads)
     out = {"metric": "reads/sec demultiplexed", "value": round(total / elapsed, 1), "unit": "reads/s", "n_gpus": 1,

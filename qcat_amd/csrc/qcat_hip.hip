@@ -1470,7 +1470,7 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
     static const char* const no_capture[] = {"QCAT_HIP_NO_GRAPH", "QCAT_HIP_DEBUG_VOTE", "QCAT_HIP_BS_TRACE", "QCAT_HIP_DEBUG_BINS", "QCAT_HIP_DEBUG_REDO"};
     bool graph_ok = !c->timing && G.failures < 2 && b->borrowed;      // (a small batch is uploaded whole into buffers of its own)
     for (const char* name : no_capture) if (getenv(name)) graph_ok = false;
-    const uint64_t gen_before = g_alloc_gen;
+    const uint64_t gen_before = g_alloc_gen.load();
     bool done = false;
     if (graph_ok && G.exec && G.kit == kit->serial && G.n_reads == n_reads && G.n_bases == b->n_bases && G.gen == gen_before && G.batch_reads == batch_reads) {
         c->packed.kit_slot_dev = chosen_dev; c->packed.kit_slot_span = slot_span;
@@ -1484,25 +1484,28 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             const int erc = enqueue();
             const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
-            if (erc == 0 && ee == hipSuccess && graph && g_alloc_gen == gen_before &&
-                hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            const bool captured = erc == 0 && ee == hipSuccess && graph != nullptr;
+            const bool moved = g_alloc_gen.load() != gen_before;     // (some context allocated meanwhile: not this call's failure)
+            if (captured && !moved && hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                 G.kit = kit->serial; G.n_reads = n_reads; G.n_bases = b->n_bases; G.gen = gen_before; G.batch_reads = batch_reads;
                 if (hipGraphLaunch(G.exec, c->stream) == hipSuccess) done = true;
             }
             if (graph) (void)hipGraphDestroy(graph);
-        }
+            if (!done && !(captured && moved)) {
+                ++G.failures;
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(c->stream);
+                packed_streams_reset(&c->packed);                // (fresh side streams: the old ones may still think they capture)
+            }
+        } else ++G.failures;
         if (!done) {                                             // (nothing of the capture ran: the plain launches below do the work)
             (void)hipGetLastError();
-            (void)hipStreamSynchronize(c->stream);
-            packed_streams_reset(&c->packed);                    // (fresh side streams: the old ones may still think they capture)
-            (void)hipGetLastError();
             if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
-            ++G.failures;
             g_fill_defer = false; g_fill.n = 0;
         }
     }
     if (!done && (rc = enqueue())) return drained(rc);
-    G.prev_kit = kit->serial; G.prev_reads = n_reads; G.prev_bases = b->n_bases; G.prev_gen = g_alloc_gen; G.prev_batch = batch_reads;
+    G.prev_kit = kit->serial; G.prev_reads = n_reads; G.prev_bases = b->n_bases; G.prev_gen = g_alloc_gen.load(); G.prev_batch = batch_reads;
     unsigned long long hv[MAX_T], hf[MAX_T];
     std::vector<int32_t> chosen((size_t)nb, -1);
     std::vector<int64_t> tmp(counts ? (size_t)hk.n_buckets : 0);

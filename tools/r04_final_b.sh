@@ -15,3 +15,4 @@ import json; d=json.loads(open('gpurun_out/r04_all/bench_$wl.json').read().strip
 done
 QCAT_BENCH_TMP=/dev/shm timeout 900 python tools/bench_auto_file.py 2000000 > gpurun_out/r04_all/auto_file.json 2>gpurun_out/r04_all/auto_file.err; cat gpurun_out/r04_all/auto_file.json
 QCAT_BENCH_TMP=/dev/shm timeout 1500 python tools/bench_cli.py 3000000 20000 > gpurun_out/r04_all/bench_cli.json 2>gpurun_out/r04_all/bench_cli.err; cat gpurun_out/r04_all/bench_cli.json | cut -c1-1500
+(QCAT_HIP_BITSLICE_MIN=2048 QCAT_HIP_ADAPTER_BITSLICE_MIN=1 timeout 1500 python tools/fuzz_bitslice.py 67 120) > gpurun_out/r04_all/fuzz_adapter_forced_67.txt 2>&1; tail -2 gpurun_out/r04_all/fuzz_adapter_forced_67.txt
