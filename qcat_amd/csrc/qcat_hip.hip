@@ -51,6 +51,15 @@ static int set_err(int rc, const std::string& m) { g_err = m; return rc; }
         if (e__ != hipSuccess)                                                               \
             return set_err(QCAT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
+// ... for code with copies in flight to or from memory that dies with the function: the stream is drained before the return
+#define HIPCHK_DRAIN(stream, expr)                                                           \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess) {                                                             \
+            (void)hipStreamSynchronize(stream);                                              \
+            return set_err(QCAT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+        }                                                                                    \
+    } while (0)
 
 extern "C" const char* qcat_last_error(void) { return g_err.c_str(); }
 extern "C" int qcat_abi_version(void) { return QCAT_ABI_VERSION; }
@@ -1475,7 +1484,7 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
     if (graph_ok && G.exec && G.kit == kit->serial && G.n_reads == n_reads && G.n_bases == b->n_bases && G.gen == gen_before && G.batch_reads == batch_reads) {
         c->packed.kit_slot_dev = chosen_dev; c->packed.kit_slot_span = slot_span;
         g_jit = kd;
-        HIPCHK(hipGraphLaunch(G.exec, c->stream));
+        HIPCHK_DRAIN(c->stream, hipGraphLaunch(G.exec, c->stream));
         ++G.replays;
         done = true;
     } else if (graph_ok && G.prev_kit == kit->serial && G.prev_reads == n_reads && G.prev_bases == b->n_bases && G.prev_gen == gen_before && G.prev_batch == batch_reads) {
@@ -1510,12 +1519,12 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
     std::vector<int32_t> chosen((size_t)nb, -1);
     std::vector<int64_t> tmp(counts ? (size_t)hk.n_buckets : 0);
     if (!batch_reads) {
-        HIPCHK(hipMemcpyAsync(hv, d, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(hf, d_first, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK_DRAIN(c->stream, hipMemcpyAsync(hv, d, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK_DRAIN(c->stream, hipMemcpyAsync(hf, d_first, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(hipMemcpyAsync(chosen.data(), chosen_dev, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(out, c->results, (size_t)n_reads * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream));
-    if (counts) HIPCHK(hipMemcpyAsync(tmp.data(), c->counts, (size_t)hk.n_buckets * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK_DRAIN(c->stream, hipMemcpyAsync(chosen.data(), chosen_dev, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK_DRAIN(c->stream, hipMemcpyAsync(out, c->results, (size_t)n_reads * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream));
+    if (counts) HIPCHK_DRAIN(c->stream, hipMemcpyAsync(tmp.data(), c->counts, (size_t)hk.n_buckets * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (!batch_reads)
         for (int t = 0; t < hk.nt; ++t) {
