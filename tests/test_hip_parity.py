@@ -422,8 +422,11 @@ def test_bit_sliced_barcode_kernels_equal_the_binary16_kernels_and_the_oracle(mo
     bases, offsets = native.pack_reads(reads)
     got = {}
     monkeypatch.setenv("QCAT_HIP_BITSLICE_MIN", "16384")     # (the path is for batches that fill the chip: force it here)
-    for variant in ("static letters", "no producer wave", "side streams", "letters from memory", "off"):
-        if variant == "no producer wave":                        # (units with an idle wave: the shared columns as a phase of their own)
+    for variant in ("static letters", "padded last super-tiles", "no producer wave", "side streams", "letters from memory", "off"):
+        if variant == "padded last super-tiles":                 # (round 4: what is left of a hot bin as one more, partly filled super-tile)
+            monkeypatch.setenv("QCAT_HIP_BITSLICE_PAD", "128")
+        elif variant == "no producer wave":                      # (units with an idle wave: the shared columns as a phase of their own)
+            monkeypatch.delenv("QCAT_HIP_BITSLICE_PAD")
             monkeypatch.setenv("QCAT_HIP_BS_NO_SOLO", "1")
             monkeypatch.setenv("QCAT_HIP_LEFTOVER_SIDE", "0")
         elif variant == "side streams":                          # (the arrangement of big batches: one stream per target family)
@@ -447,6 +450,38 @@ def test_bit_sliced_barcode_kernels_equal_the_binary16_kernels_and_the_oracle(mo
         assert ("k_barcode_bitslice" in ran) == (variant != "off"), (variant, ran)
         bad = np.nonzero(got[variant] != want)[0]
         assert len(bad) == 0, (variant, bad[:10], got[variant][bad[:3]], want[bad[:3]])
+        assert np.array_equal(cnt, want_cnt)
+
+
+@pytest.mark.parametrize("n", [1100, 4000, 9000])
+def test_small_batches_of_a_96_barcode_kit_on_padded_super_tiles(n, monkeypatch):
+    """Round 4 (measured, not the default: DESIGN 9.4): with QCAT_HIP_BITSLICE_PAD=<jobs> a small batch of a big barcode set
+    runs its hot jobs on the bit-sliced kernels with one partly filled super-tile per hot bin.  The records are the oracle's
+    with the padding and without it, and with the padding the bit-sliced kernels must really have run."""
+    det = scanner.factory(mode="epi2me", kit="PBC096")
+    reads = synth.synth_batch(n, 4242 + n, det.layouts, 1, 0, error_rate=0.08)
+    for i in range(0, n, 13):
+        reads[i] = reads[i][:50] + "N" + reads[i][51:] if i % 2 else reads[i][:120 + i % 300]
+    d = det.descriptor(ends=native.ENDS_BOTH)
+    want, want_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
+    bases, offsets = native.pack_reads(reads)
+    lib = native.HipLibrary.get().lib
+    for pad in ("256", None):
+        if pad is not None:
+            monkeypatch.setenv("QCAT_HIP_BITSLICE_PAD", pad)
+        else:
+            monkeypatch.delenv("QCAT_HIP_BITSLICE_PAD")
+        ctx = native.NativeContext(0)
+        native.HipLibrary.get().check(lib.qcat_ctx_set_timing(ctx.handle, 1))
+        cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+        got = ctx.scan(native.NativeKit(d), bases, offsets, counts=cnt)
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        k = lib.qcat_ctx_last_timing(ctx.handle, names, ms, 16)
+        ran = [names[i].decode() for i in range(k)]
+        assert ("k_barcode_bitslice" in ran) == (pad is not None and 2 * n >= 2048), (pad, ran)
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (pad, bad[:10], got[bad[:3]], want[bad[:3]])
         assert np.array_equal(cnt, want_cnt)
 
 
