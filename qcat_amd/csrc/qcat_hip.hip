@@ -706,7 +706,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
             c->packed.lazy = lazy;
             hipLaunchKernelGGL(k_pack_windows, dim3(blocks), dim3(256), 0, c->stream,
                                b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen, c->wspec, c->win2, lazy ? 1 : 0);
-            if (lazy) hipLaunchKernelGGL(k_expand_special, dim3(blocks), dim3(256), 0, c->stream,
+            if (lazy) hipLaunchKernelGGL(k_expand_special, dim3((uint32_t)((n_ends + 255) / 256)), dim3(256), 0, c->stream,
                                          b->bases, b->offsets, n, ends, hk.max_align, c->wspec, c->win);
         }
         mark(c, "k_pack_windows");
