@@ -382,6 +382,13 @@ void* qcat_ctx_stream(qcat_ctx* ctx);
  * and tests; -1: null context. */
 int64_t qcat_ctx_graph_replays(const qcat_ctx* ctx);
 
+/* Diagnostics of the context's latest --detect-middle scan (detect_barcode's interior scan, qcat/scanner_base.py:479-519,
+ * :593-595): out[0] = tiles of 2048 interiors whose adapter scan ran in bit-sliced form (csrc/kernels_abs_mid.inc), out[1] =
+ * such tiles in all, out[2] = tiles of 128 interiors left to the binary16 kernel (a letter outside A, C, G, T, a kit without
+ * plans, no room in the plane buffer), out[3] = tiles of 128 in all; all zero when the batch was too small for the path or
+ * QCAT_HIP_MIDDLE_NO_ABS=1.  Synchronises the context's stream.  Tests and diagnostics. */
+int qcat_ctx_middle_bitslice_tiles(qcat_ctx* ctx, uint32_t out[4]);
+
 /* Kernel timing, measured with hipEvents recorded on the context's stream around each kernel
  * phase: the AVERAGE over the qcat_scan_resident calls since the previous qcat_ctx_last_timing /
  * qcat_ctx_set_timing (a ring of 64 scans; scans need no host synchronisation between them, this

@@ -59,12 +59,20 @@ namespace qabs {
 
 constexpr int ABS_NP = 4;        // planes of a difference (0..9)
 constexpr int ABS_NF = 10;       // planes of a deficit counter / of the last-row sum: <= 7 * 128 < 1024
-constexpr int ABS_NI = 8;        // planes of a row index (< 256)
+#ifndef QCAT_ABS_NI
+#define QCAT_ABS_NI 8
+#endif
+constexpr int ABS_NI = QCAT_ABS_NI;   // planes of a row index: 8 for the read ends' windows (< 256 rows); the translation unit of the interior
+                                      // scan (abs_mid_kernels.hip, --detect-middle) is compiled with 14 (interiors up to 16 384 rows)
 constexpr int ABS_G = 2;         // the gap cost the form is built on (open == extend == 2)
 constexpr int ABS_W_MATCH = 9, ABS_W_MISMATCH = 2, ABS_W_N = 3;       // W + 2g
 
 // difference planes of the boundary: G(i,0) = 2i, G(0,j) = 2j -> every boundary difference is 2
 ABS_FN void abs_set2(u32 (&v)[ABS_NP]) { v[0] = 0u; v[1] = 0xFFFFFFFFu; v[2] = 0u; v[3] = 0u; }
+
+// v = hold ? 2 : v -- an alignment that has not started yet (front padding of the interior scan, kernels_abs_mid.inc) keeps the
+// boundary state of row 0 whatever the row computed for it
+ABS_FN void abs_hold2(u32 (&v)[ABS_NP], u32 hold) { v[0] &= ~hold; v[1] |= hold; v[2] &= ~hold; v[3] &= ~hold; }
 
 // max(a, b) -> mx, through the borrow chain of a - b (lt = [a < b]) and four selects
 ABS_FN void abs_max(const u32 (&a)[ABS_NP], const u32 (&b)[ABS_NP], u32 (&mx)[ABS_NP]) {

@@ -1,0 +1,32 @@
+// abs_mid_kernels.hip -- the bit-sliced interior adapter scan of --detect-middle (kernels_abs_mid.inc) in a translation unit
+// of its own: __graft_entry__.build() compiles this file with -Dqk=qk_absmid -Dqabs=qabs_mid -DQCAT_ABS_NI=14 (row indices of
+// interiors up to 16 384 rows; abs_kernels.hip keeps the eight index planes of the read ends' windows) and qcat_hip.hip
+// reaches the kernels through the extern "C" launchers below (declared in qcat_hip.hip beside middle_packed).
+#include <hip/hip_runtime.h>
+
+#include "rtc_prelude.inc"
+#include "kernels_abs.inc"
+#include "kernels_abs_mid.inc"
+
+static_assert(qabs::ABS_NI >= 14, "compile with -DQCAT_ABS_NI=14: interiors of up to 16 384 rows");
+
+// row counts, places and letter planes of the big tiles (k_absmid_tiles, k_absmid_scan, k_absmid_planes)
+extern "C" void qcat_absmid_prepare(void* stream, const void* args) {
+    const qk::AbsMidArgs& a = *static_cast<const qk::AbsMidArgs*>(args);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(qk::k_absmid_tiles, dim3(a.n_tiles), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(qk::k_absmid_scan, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(qk::k_absmid_planes, dim3(a.n_tiles, qk::ABSM_GY), dim3(256), 0, s, a);
+}
+
+// the two-stage plan of adapter template `id` (g_static_templates) over the big tiles of its kit.  Returns 0 when the plan
+// does not exist; args null: only asks
+extern "C" int qcat_absmid_launch(int id, unsigned grid, void* stream, const void* args) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (id) {
+#define QCAT_ABS_CASE(N) case N: if (args) hipLaunchKernelGGL(qk::k_adapter_mid<qabs::QAB_T##N>, dim3(grid), dim3(128), 0, s, *static_cast<const qk::AbsMidArgs*>(args)); return 1;
+        QCAT_ABS_FOR_EACH_TEMPLATE(QCAT_ABS_CASE)
+#undef QCAT_ABS_CASE
+    default: return 0;
+    }
+}

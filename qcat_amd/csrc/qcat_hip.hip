@@ -429,6 +429,13 @@ struct qcat_ctx {
     uint32_t* mid_win2 = nullptr; uint8_t* mid_wspec = nullptr;   // the M-ends' first window at two bits per code + flags (k_mid_windows)
     EndRec* mid_recs = nullptr; AdapterBest* mid_bests = nullptr;
     size_t cap_mid_slots = 0, cap_mid_bests = 0;
+    // ... its bit-sliced adapter scan (kernels_abs_mid.inc): per big tile of 2048 slots [rows, padding zone, kit, first row: 4 x tiles]
+    // [nonempty, invalid: 2 x 64 x tiles] [cursors: MAX_T], the per-128 flags, letter planes and not-started masks
+    uint32_t* absm_tiles = nullptr; size_t cap_absm_tiles = 0;
+    uint8_t* absm_need = nullptr; size_t cap_absm_need = 0;
+    uint2* absm_planes = nullptr; size_t cap_absm_planes = 0;
+    uint32_t* absm_ns = nullptr; size_t cap_absm_ns = 0;
+    uint32_t absm_last_big = 0, absm_last_128 = 0;                // big tiles / tiles of 128 slots of the latest scan on that path (0: not taken)
     uint32_t last_n_reads = 0;
     int last_buckets = 0;
     // device staging of the host-buffer calls (qcat_scan_batch / _auto / _debug, qcat_detect_kit): grown on demand and
@@ -497,6 +504,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     (void)hipFree(c->mid_tables); (void)hipFree(c->mid_generic); (void)hipFree(c->mid_slot); (void)hipFree(c->mid_sorted);
     (void)hipFree(c->mid_len); (void)hipFree(c->mid_fallback); (void)hipFree(c->mid_recs); (void)hipFree(c->mid_bests);
     (void)hipFree(c->mid_win2); (void)hipFree(c->mid_wspec);
+    (void)hipFree(c->absm_tiles); (void)hipFree(c->absm_need); (void)hipFree(c->absm_planes); (void)hipFree(c->absm_ns);
     if (c->ev_ready) for (int r = 0; r < qcat_ctx::TIME_RING; ++r) for (int i = 0; i <= MAX_TIMED; ++i) (void)hipEventDestroy(c->evr[r][i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -542,6 +550,22 @@ static bool middle_packed_ok(const DevKit& hk) {
     if (hk.adapter_f16_headroom < hk.gap_open * 119 + 1) return false;
     for (int t = 0; t < hk.nt; ++t) if (hk.tpl[t].static_kernel < 0) return false;
     return true;
+}
+
+// the bit-sliced interior adapter scan (kernels_abs_mid.inc, abs_mid_kernels.hip)
+extern "C" void qcat_absmid_prepare(void* stream, const void* args);
+extern "C" int qcat_absmid_launch(int id, unsigned grid, void* stream, const void* args);
+
+// kit slots whose templates all have a two-stage bit-sliced plan (the built-in kits' single-template plans)
+static uint32_t absmid_kit_mask(const DevKit& hk) {
+    if (!hk.abs_ok) return 0u;
+    uint32_t mask = 0u, bad = 0u;
+    for (int t = 0; t < hk.nt; ++t) {
+        const int ks = hk.tpl[t].kit_slot, sk = hk.tpl[t].static_kernel;
+        if (ks < 0 || ks >= 32) continue;
+        if (sk >= 0 && sk < QCAT_JIT_BASE && qcat_absmid_launch(sk, 0, nullptr, nullptr)) mask |= 1u << ks; else bad |= 1u << ks;
+    }
+    return mask & ~bad;
 }
 
 // the interior scan of every called read on the packed kernels (kernels_middle.inc); leaves
@@ -596,9 +620,54 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     sc->slim = false;                                     // ... and the barcode results stay in the interior's own records
     if ((rc = packed_prepare(st, hk, (uint32_t)slots, sc))) return set_err(rc, packed_last_error());
     const uint32_t tiles = (uint32_t)(slots / PK_TILE);
+    // round 4: the adapter scan of the interiors in bit-sliced form (kernels_abs_mid.inc) from QCAT_HIP_MIDDLE_ABS_MIN slots
+    // (default: one big tile of 2048 slots per CU); QCAT_HIP_MIDDLE_NO_ABS=1: the binary16 kernel for every tile as before.
+    // The binary16 kernel then only takes the tiles of 128 slots flagged in absm_need.
+    AbsMidArgs am{};
+    bool use_absm = false;
+    c->absm_last_big = 0; c->absm_last_128 = 0;
+    {
+        const char* amin = getenv("QCAT_HIP_MIDDLE_ABS_MIN");
+        const size_t min_slots = amin ? (size_t)atoll(amin) : (size_t)abs_cu_count() * 2048;
+        const uint32_t kmask = getenv("QCAT_HIP_MIDDLE_NO_ABS") ? 0u : absmid_kit_mask(hk);
+        if (kmask && slots >= min_slots) {
+            const uint32_t big = (uint32_t)((slots + 2047) / 2048);
+            // rows of all big tiles together: every tile as long as its longest interior -- the mean of the interiors plus
+            // the width of the length classes a tile spans; a tile beyond the room falls back to the binary16 kernel
+            const char* rcap = getenv("QCAT_HIP_MIDDLE_ABS_ROWS");         // (tests: a plane buffer that is too small)
+            const size_t rows = rcap ? (size_t)atoll(rcap)
+                                     : std::min<size_t>((size_t)1 << 30, (size_t)(2 * b->n_bases / 2048) * 5 / 4 + (size_t)big * 128 + 16384 + 64);
+            const size_t tw = (size_t)big * (4 + 128) + MAX_T;
+            if ((rc = grow(&c->absm_tiles, &c->cap_absm_tiles, tw))) return rc;
+            if ((rc = grow(&c->absm_need, &c->cap_absm_need, (size_t)tiles + 16))) return rc;
+            if ((rc = grow(&c->absm_planes, &c->cap_absm_planes, rows * 64))) return rc;
+            if ((rc = grow(&c->absm_ns, &c->cap_absm_ns, rows * 64))) return rc;
+            uint32_t* w = c->absm_tiles;
+            am.bases = b->bases; am.offsets = b->offsets; am.msorted = c->mid_sorted; am.mlen = c->mid_len; am.mt = c->mid_tables;
+            am.max_align = hk.max_align; am.n_tiles = big; am.slot_cap = (uint32_t)slots; am.nt = hk.nt; am.kit_mask = kmask;
+            am.t_rows = (int32_t*)w; am.t_pz = (int32_t*)(w + big); am.t_kit = (int32_t*)(w + 2 * (size_t)big); am.t_off = w + 3 * (size_t)big;
+            am.nonempty = w + 4 * (size_t)big; am.invalid = w + 4 * (size_t)big + 64 * (size_t)big;
+            am.cursor = w + (size_t)big * (4 + 128);
+            am.need128 = c->absm_need; am.planes = c->absm_planes; am.ns = c->absm_ns; am.row_cap = (uint32_t)rows;
+            am.bests = c->mid_bests; am.tpl = -1; am.den = 0; am.kit_slot = -1;
+            const char* pr = getenv("QCAT_HIP_ABS_PRIO");
+            am.prio = pr ? atoi(pr) : 0;
+            HIPCHK(hipMemsetAsync(am.cursor, 0, MAX_T * 4, st));
+            qcat_absmid_prepare(st, &am);
+            use_absm = true;
+            c->absm_last_big = big; c->absm_last_128 = tiles;
+        }
+    }
     fork_join(sc, st, hk.nt, [&](int t, hipStream_t q) {
+        if (use_absm && ((am.kit_mask >> hk.tpl[t].kit_slot) & 1u)) {
+            AbsMidArgs at = am;
+            at.bests = c->mid_bests + (size_t)t * slots; at.tpl = t; at.den = hk.tpl[t].den; at.kit_slot = hk.tpl[t].kit_slot;
+            at.cursor = am.cursor + t;
+            const unsigned grid = (unsigned)std::min<uint32_t>(am.n_tiles, (uint32_t)abs_cu_count() * 4u);
+            (void)qcat_absmid_launch(hk.tpl[t].static_kernel, grid, q, &at);
+        }
         MiddleAdapterArgs ma{kp, b->bases, b->offsets, c->mid_sorted, c->mid_len, c->mid_tables,
-                             c->mid_bests + (size_t)t * slots, t};
+                             c->mid_bests + (size_t)t * slots, t, use_absm ? c->absm_need : nullptr};
         launch_adapter_middle(hk.tpl[t].static_kernel, dim3(tiles), q, ma);
     });
     {
@@ -803,6 +872,24 @@ extern "C" int qcat_ctx_fetch_counts(qcat_ctx* c, int64_t* counts, int32_t n_buc
 
 extern "C" void* qcat_ctx_stream(qcat_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int64_t qcat_ctx_graph_replays(const qcat_ctx* c) { return c ? (int64_t)c->api_graph.replays : -1; }
+// diagnostics of the latest --detect-middle scan: out[0] = big tiles (2048 interiors) its bit-sliced adapter scan walked, out[1] = big
+// tiles in all, out[2] = tiles of 128 interiors left to the binary16 kernel, out[3] = tiles of 128 in all (all 0: path not taken)
+extern "C" int qcat_ctx_middle_bitslice_tiles(qcat_ctx* c, uint32_t* out) {
+    if (!c || !out) return set_err(QCAT_ERR_ARG, "null argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!c->absm_last_big) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    std::vector<int32_t> rows(c->absm_last_big);
+    std::vector<uint8_t> need(c->absm_last_128);
+    HIPCHK(hipMemcpy(rows.data(), c->absm_tiles, rows.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(need.data(), c->absm_need, need.size(), hipMemcpyDeviceToHost));
+    for (int32_t r : rows) if (r > 0) ++out[0];
+    out[1] = c->absm_last_big;
+    for (uint8_t f : need) if (f) ++out[2];
+    out[3] = c->absm_last_128;
+    return 0;
+}
 extern "C" void* qcat_ctx_counts_devptr(qcat_ctx* c) { return c ? c->counts : nullptr; }
 extern "C" void* qcat_ctx_results_devptr(qcat_ctx* c) { return c ? c->results : nullptr; }
 

@@ -123,6 +123,77 @@ static int check_plan(const char* name, const std::string* tpls, int rounds, int
     return bad;
 }
 
+// the interior scan's form of a single-template plan (kernels_abs_mid.inc: abs_mid_body): 32 queries of unequal length, padded
+// at the FRONT to the longest (L rows); an alignment that has not started is held at the boundary state after every row, its
+// first row forces the border walk, its end position is the tile row minus its padding.  The same calls in the same order
+// as the two pipeline stages make them.
+template <class P>
+static int check_padded(const char* name, const std::string* tpls, int rounds, int L) {
+    static_assert(P::NT == 1 && P::NH == 1, "single-template plans");
+    int8_t mat[49];
+    adapter_matrix(mat);
+    int bad = 0;
+    for (int r = 0; r < rounds; ++r) {
+        std::vector<std::string> win(32);
+        int len[32], pz = 0;
+        const int spread = r % 3 == 0 ? 0 : (r % 3 == 1 ? 70 : L - 1);          // equal lengths / a length class / anything down to one base
+        for (int b = 0; b < 32; ++b) {
+            len[b] = b == 0 ? L : L - (spread ? below(spread + 1) : 0);
+            win[(size_t)b] = make_window(tpls, 1, len[b]);
+            if (L - len[b] > pz) pz = L - len[b];
+        }
+        std::vector<u32> c1((size_t)L), c0((size_t)L), ns((size_t)L);
+        for (int i = 0; i < L; ++i)
+            for (int b = 0; b < 32; ++b) {
+                const int pad = L - len[b];
+                if (i < pad) { ns[(size_t)i] |= 1u << b; if (rnd() & 1) c1[(size_t)i] |= 1u << b; continue; }     // (whatever letters: the hold wipes them)
+                const int code = (int)(strchr(BASES, win[(size_t)b][(size_t)(i - pad)]) - BASES);
+                c1[(size_t)i] |= (u32)((code >> 1) & 1) << b;
+                c0[(size_t)i] |= (u32)(code & 1) << b;
+            }
+        static u32 h0[P::NC0][4], h1[P::NC1][4];
+        for (int j = 0; j < P::NC0; ++j) abs_set2(h0[j]);
+        for (int j = 0; j < P::NC1; ++j) abs_set2(h1[j]);
+        AbsBorder bd[1];
+        memset(bd, 0, sizeof bd);
+        u32 prev_ns = 0xFFFFFFFFu;
+        for (int i = 0; i < L; ++i) {
+            u32 nq[4], ho[1][4];
+            const u32 nsm = i < pz ? ns[(size_t)i] : 0u;
+            abs_neq_masks(c1[(size_t)i], c0[(size_t)i], nq);
+            P::row0(nq, h0, ho);
+            if (i < pz) { for (int j = 0; j < P::NC0; ++j) abs_hold2(h0[j], nsm); abs_hold2(ho[0], nsm); }
+            const u32 first = prev_ns & ~nsm;
+            prev_ns = nsm;
+            P::row1(nq, h1, ho, bd, first, (unsigned)i);
+            if (i < pz) for (int j = 0; j < P::NC1; ++j) abs_hold2(h1[j], nsm);
+        }
+        AbsLastRow lo[1], lr[1];
+        P::last0(h0, lo);
+        P::last1(h1, lo, lr);
+        u32 val[ABS_NF + 1], endq[ABS_NI];
+        abs_decide(bd[0], lr[0], (unsigned)(L - 1), val, endq);
+        const int M = (int)tpls[0].size();
+        for (int b = 0; b < 32; ++b) {
+            int v = 0, e = 0;
+            for (int k = 0; k <= ABS_NF; ++k) v |= (int)((val[k] >> b) & 1u) << k;
+            for (int k = 0; k < ABS_NI; ++k) e |= (int)((endq[k] >> b) & 1u) << k;
+            const int score = v - 2 * M - 1;
+            e -= L - len[b];
+            int32_t ws, wq, wr;
+            qo_sg(win[(size_t)b].c_str(), len[b], tpls[0].c_str(), M, 2, 2, mat, &ws, &wq, &wr);
+            if (score != ws || e != wq) {
+                if (bad < 10)
+                    fprintf(stderr, "%s padded round %d alignment %d (len %d of %d): got (%d, %d), oracle (%d, %d)\n  %s\n", name, r, b, len[b], L,
+                            score, e, ws, wq, win[(size_t)b].c_str());
+                ++bad;
+            }
+        }
+    }
+    printf("%s front-padded: %d rounds x 32 alignments of unequal length, L = %d: %d mismatches\n", name, rounds, L, bad);
+    return bad;
+}
+
 // a plan of four stages (QAM_*): the stages of a row one after the other, each handing its differences to the next
 template <class P>
 static int check_multi(const char* name, const std::string* tpls, int rounds, int L) {

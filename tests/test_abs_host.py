@@ -12,11 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-@pytest.fixture(scope="module")
-def host_check(tmp_path_factory):
+@pytest.fixture(scope="module", params=[8, 14], ids=["windows", "interiors"])
+def host_check(request, tmp_path_factory):
+    """8 row-index planes: the build of abs_kernels.hip (read-end windows); 14: that of abs_mid_kernels.hip (read interiors,
+    --detect-middle), whose front-padded form then runs 611 rows"""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     exe = str(tmp_path_factory.mktemp("abs") / "abs_host_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-I", os.path.join(ROOT, "qcat_amd", "csrc"), "-I", os.path.join(ROOT, "tests"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-DQCAT_ABS_NI=%d" % request.param,
+                           "-I", os.path.join(ROOT, "qcat_amd", "csrc"), "-I", os.path.join(ROOT, "tests"),
                            os.path.join(ROOT, "tests", "abs_host_check.cpp"), "-o", exe,
                            "-L", os.path.join(ROOT, "oracle"), "-lqcat_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
     return exe
@@ -29,6 +32,7 @@ def test_bit_sliced_adapter_arithmetic_equals_the_oracle_dp(host_check, seed):
     assert p.returncode == 0, out[-2000:] + p.stderr.decode()[-2000:]
     lines = [l for l in out.splitlines() if l.strip()]
     assert len(lines) >= 1 + 2 * 15 and all(l.endswith(": 0 mismatches") for l in lines), out[-2000:]
+    assert sum("front-padded" in l for l in lines) >= 10, out[-2000:]
 
 
 def test_generated_plans_are_in_sync_with_the_kit_bundle():

@@ -218,6 +218,28 @@ def test_packed_detect_middle_matches_generic_kernel_and_oracle(monkeypatch, mod
     assert recs.tobytes() == o_recs.tobytes()
     assert np.array_equal(cnt, o_cnt)
     assert (recs["exit_status"] == 997).sum() > 20
+    # the bit-sliced interior adapter scan (kernels_abs_mid.inc; big batches only by default) forced onto this batch: one big
+    # tile holds every length class (front padding of hundreds of rows), the N runs go back to the binary16 kernel per tile
+    # of 128; then with a plane buffer that holds no tile / only the first ones (the rest falls back)
+    import ctypes
+    lib = native.HipLibrary.get().lib
+    tiles = (ctypes.c_uint32 * 4)()
+    assert lib.qcat_ctx_middle_bitslice_tiles(ctx().handle, tiles) == 0 and list(tiles) == [0, 0, 0, 0]
+    for rows_cap, on_path in ((None, True), ("10", False), ("3000", None)):
+        with monkeypatch.context() as m:
+            m.setenv("QCAT_HIP_MIDDLE_ABS_MIN", "1")
+            if rows_cap:
+                m.setenv("QCAT_HIP_MIDDLE_ABS_ROWS", rows_cap)
+            cnt_b = np.zeros(d.n_count_buckets, dtype=np.int64)
+            recs_b = ctx().scan(kit_h, bases, offsets, counts=cnt_b)
+            assert lib.qcat_ctx_middle_bitslice_tiles(ctx().handle, tiles) == 0
+        assert recs_b.tobytes() == o_recs.tobytes(), (rows_cap, list(tiles))
+        assert np.array_equal(cnt_b, o_cnt)
+        assert tiles[1] >= 1 and tiles[3] >= tiles[1]
+        if on_path is True:
+            assert tiles[0] >= 1 and 1 <= tiles[2] < tiles[3], list(tiles)       # (the N runs: some tiles of 128, not all)
+        if on_path is False:
+            assert tiles[0] == 0 and tiles[2] >= 1, list(tiles)
 
 
 @gpu
