@@ -3,6 +3,7 @@
 // interiors up to 16 384 rows; abs_kernels.hip keeps the eight index planes of the read ends' windows) and qcat_hip.hip
 // reaches the kernels through the extern "C" launchers below (declared in qcat_hip.hip beside middle_packed).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "rtc_prelude.inc"
 #include "kernels_abs.inc"
@@ -10,10 +11,12 @@
 
 static_assert(qabs::ABS_NI >= 14, "compile with -DQCAT_ABS_NI=14: interiors of up to 16 384 rows");
 
-// row counts, places and letter planes of the big tiles (k_absmid_tiles, k_absmid_scan, k_absmid_planes)
+// row counts, places and letter planes of the big tiles (k_absmid_codes, k_absmid_tiles, k_absmid_scan, k_absmid_planes); rspec zeroed by the caller
 extern "C" void qcat_absmid_prepare(void* stream, const void* args) {
     const qk::AbsMidArgs& a = *static_cast<const qk::AbsMidArgs*>(args);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned long long chunks = (a.n_bases + 15) / 16 + 1;
+    hipLaunchKernelGGL(qk::k_absmid_codes, dim3((unsigned)std::min<unsigned long long>((chunks + 255) / 256, 1u << 20)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(qk::k_absmid_tiles, dim3(a.n_tiles), dim3(256), 0, s, a);
     hipLaunchKernelGGL(qk::k_absmid_scan, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(qk::k_absmid_planes, dim3(a.n_tiles, qk::ABSM_GY), dim3(256), 0, s, a);

@@ -435,6 +435,9 @@ struct qcat_ctx {
     uint8_t* absm_need = nullptr; size_t cap_absm_need = 0;
     uint2* absm_planes = nullptr; size_t cap_absm_planes = 0;
     uint32_t* absm_ns = nullptr; size_t cap_absm_ns = 0;
+    uint32_t* absm_c2 = nullptr; size_t cap_absm_c2 = 0;          // the batch at two bits per base (with ABSM_C2_SLACK dwords on either side)
+    uint8_t* absm_rspec = nullptr; size_t cap_absm_rspec = 0;
+    uint64_t* absm_sinfo = nullptr; size_t cap_absm_sinfo = 0;
     uint32_t absm_last_big = 0, absm_last_128 = 0;                // big tiles / tiles of 128 slots of the latest scan on that path (0: not taken)
     uint32_t last_n_reads = 0;
     int last_buckets = 0;
@@ -505,6 +508,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     (void)hipFree(c->mid_len); (void)hipFree(c->mid_fallback); (void)hipFree(c->mid_recs); (void)hipFree(c->mid_bests);
     (void)hipFree(c->mid_win2); (void)hipFree(c->mid_wspec);
     (void)hipFree(c->absm_tiles); (void)hipFree(c->absm_need); (void)hipFree(c->absm_planes); (void)hipFree(c->absm_ns);
+    (void)hipFree(c->absm_c2); (void)hipFree(c->absm_rspec); (void)hipFree(c->absm_sinfo);
     if (c->ev_ready) for (int r = 0; r < qcat_ctx::TIME_RING; ++r) for (int i = 0; i <= MAX_TIMED; ++i) (void)hipEventDestroy(c->evr[r][i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -642,12 +646,18 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             if ((rc = grow(&c->absm_need, &c->cap_absm_need, (size_t)tiles + 16))) return rc;
             if ((rc = grow(&c->absm_planes, &c->cap_absm_planes, rows * 64))) return rc;
             if ((rc = grow(&c->absm_ns, &c->cap_absm_ns, rows * 64))) return rc;
+            constexpr size_t C2_SLACK = 1040;                                   // = ABSM_C2_SLACK (kernels_abs_mid.inc)
+            if ((rc = grow(&c->absm_c2, &c->cap_absm_c2, (size_t)(b->n_bases / 16) + 4 + 2 * C2_SLACK))) return rc;
+            if ((rc = grow(&c->absm_rspec, &c->cap_absm_rspec, (size_t)n + 1))) return rc;
+            if ((rc = grow(&c->absm_sinfo, &c->cap_absm_sinfo, slots))) return rc;
             uint32_t* w = c->absm_tiles;
             am.bases = b->bases; am.offsets = b->offsets; am.msorted = c->mid_sorted; am.mlen = c->mid_len; am.mt = c->mid_tables;
             am.max_align = hk.max_align; am.n_tiles = big; am.slot_cap = (uint32_t)slots; am.nt = hk.nt; am.kit_mask = kmask;
             am.t_rows = (int32_t*)w; am.t_pz = (int32_t*)(w + big); am.t_kit = (int32_t*)(w + 2 * (size_t)big); am.t_off = w + 3 * (size_t)big;
             am.nonempty = w + 4 * (size_t)big; am.invalid = w + 4 * (size_t)big + 64 * (size_t)big;
             am.cursor = w + (size_t)big * (4 + 128);
+            am.c2 = c->absm_c2 + C2_SLACK; am.rspec = c->absm_rspec; am.sinfo = c->absm_sinfo; am.n_bases = b->n_bases; am.n_reads = n;
+            HIPCHK(hipMemsetAsync(c->absm_rspec, 0, (size_t)n + 1, st));
             am.need128 = c->absm_need; am.planes = c->absm_planes; am.ns = c->absm_ns; am.row_cap = (uint32_t)rows;
             am.bests = c->mid_bests; am.tpl = -1; am.den = 0; am.kit_slot = -1;
             const char* pr = getenv("QCAT_HIP_ABS_PRIO");
@@ -658,12 +668,19 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             c->absm_last_big = big; c->absm_last_128 = tiles;
         }
     }
+    int absm_side = 0;                                             // templates on the bit-sliced path: launches side by side
+    if (use_absm) for (int t = 0; t < hk.nt; ++t) if ((am.kit_mask >> hk.tpl[t].kit_slot) & 1u) ++absm_side;
     fork_join(sc, st, hk.nt, [&](int t, hipStream_t q) {
         if (use_absm && ((am.kit_mask >> hk.tpl[t].kit_slot) & 1u)) {
             AbsMidArgs at = am;
             at.bests = c->mid_bests + (size_t)t * slots; at.tpl = t; at.den = hk.tpl[t].den; at.kit_slot = hk.tpl[t].kit_slot;
             at.cursor = am.cursor + t;
-            const unsigned grid = (unsigned)std::min<uint32_t>(am.n_tiles, (uint32_t)abs_cu_count() * 4u);
+            // persistent two-wave workgroups: four per CU (two waves per SIMD) shared by the templates that run side by side --
+            // two launches of four per CU each do not fit the register file together, and the second one then runs after
+            // the first (1.2 + 0.6 ms at 1 M reads against ~1.0 ms side by side).  QCAT_HIP_MIDDLE_ABS_WGS=<per CU and launch>
+            const char* wg = getenv("QCAT_HIP_MIDDLE_ABS_WGS");
+            const int per_cu = wg ? atoi(wg) : std::max(1, 4 / std::max(1, absm_side));
+            const unsigned grid = (unsigned)std::min<uint32_t>(am.n_tiles, (uint32_t)(abs_cu_count() * per_cu));
             (void)qcat_absmid_launch(hk.tpl[t].static_kernel, grid, q, &at);
         }
         MiddleAdapterArgs ma{kp, b->bases, b->offsets, c->mid_sorted, c->mid_len, c->mid_tables,
