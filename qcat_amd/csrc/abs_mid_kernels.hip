@@ -22,12 +22,20 @@ extern "C" void qcat_absmid_prepare(void* stream, const void* args) {
     hipLaunchKernelGGL(qk::k_absmid_planes, dim3(a.n_tiles, qk::ABSM_GY), dim3(256), 0, s, a);
 }
 
-// the two-stage plan of adapter template `id` (g_static_templates) over the big tiles of its kit.  Returns 0 when the plan
-// does not exist; args null: only asks
-extern "C" int qcat_absmid_launch(int id, unsigned grid, void* stream, const void* args) {
+// the single-template plan of adapter template `id` (g_static_templates) over the big tiles of its kit.  waves 2: the two-stage
+// pipeline (k_adapter_mid, workgroups of 128); waves 1: the whole row on one wave (k_adapter_mid1, workgroups of 64) -- only
+// for templates of up to ABSM_ONE_WAVE_COLS columns.  Returns 0 when that form does not exist; args null: only asks
+extern "C" int qcat_absmid_launch(int id, int waves, unsigned grid, void* stream, const void* args) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (id) {
-#define QCAT_ABS_CASE(N) case N: if (args) hipLaunchKernelGGL(qk::k_adapter_mid<qabs::QAB_T##N>, dim3(grid), dim3(128), 0, s, *static_cast<const qk::AbsMidArgs*>(args)); return 1;
+#define QCAT_ABS_CASE(N) case N: \
+        if (waves == 1) { \
+            if (qabs::QAB_T##N::NC0 + qabs::QAB_T##N::NC1 > qk::ABSM_ONE_WAVE_COLS) return 0; \
+            if (args) hipLaunchKernelGGL(qk::k_adapter_mid1<qabs::QAB_T##N>, dim3(grid), dim3(64), 0, s, *static_cast<const qk::AbsMidArgs*>(args)); \
+            return 1; \
+        } \
+        if (args) hipLaunchKernelGGL(qk::k_adapter_mid<qabs::QAB_T##N>, dim3(grid), dim3(128), 0, s, *static_cast<const qk::AbsMidArgs*>(args)); \
+        return 1;
         QCAT_ABS_FOR_EACH_TEMPLATE(QCAT_ABS_CASE)
 #undef QCAT_ABS_CASE
     default: return 0;

@@ -558,7 +558,7 @@ static bool middle_packed_ok(const DevKit& hk) {
 
 // the bit-sliced interior adapter scan (kernels_abs_mid.inc, abs_mid_kernels.hip)
 extern "C" void qcat_absmid_prepare(void* stream, const void* args);
-extern "C" int qcat_absmid_launch(int id, unsigned grid, void* stream, const void* args);
+extern "C" int qcat_absmid_launch(int id, int waves, unsigned grid, void* stream, const void* args);
 
 // kit slots whose templates all have a two-stage bit-sliced plan (the built-in kits' single-template plans)
 static uint32_t absmid_kit_mask(const DevKit& hk) {
@@ -567,7 +567,7 @@ static uint32_t absmid_kit_mask(const DevKit& hk) {
     for (int t = 0; t < hk.nt; ++t) {
         const int ks = hk.tpl[t].kit_slot, sk = hk.tpl[t].static_kernel;
         if (ks < 0 || ks >= 32) continue;
-        if (sk >= 0 && sk < QCAT_JIT_BASE && qcat_absmid_launch(sk, 0, nullptr, nullptr)) mask |= 1u << ks; else bad |= 1u << ks;
+        if (sk >= 0 && sk < QCAT_JIT_BASE && qcat_absmid_launch(sk, 2, 0, nullptr, nullptr)) mask |= 1u << ks; else bad |= 1u << ks;
     }
     return mask & ~bad;
 }
@@ -678,10 +678,14 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             // persistent two-wave workgroups: four per CU (two waves per SIMD) shared by the templates that run side by side --
             // two launches of four per CU each do not fit the register file together, and the second one then runs after
             // the first (1.2 + 0.6 ms at 1 M reads against ~1.0 ms side by side).  QCAT_HIP_MIDDLE_ABS_WGS=<per CU and launch>
+            // A template of up to 46 columns walks a tile on ONE wave (k_adapter_mid1: eight per CU); QCAT_HIP_MIDDLE_ABS_ONE_WAVE=0: pipeline.
             const char* wg = getenv("QCAT_HIP_MIDDLE_ABS_WGS");
-            const int per_cu = wg ? atoi(wg) : std::max(1, 4 / std::max(1, absm_side));
+            const char* ow = getenv("QCAT_HIP_MIDDLE_ABS_ONE_WAVE");
+            const int sk = hk.tpl[t].static_kernel;
+            const bool one = !(ow && atoi(ow) == 0) && qcat_absmid_launch(sk, 1, 0, nullptr, nullptr) != 0;
+            const int per_cu = wg ? atoi(wg) : std::max(1, (one ? 8 : 4) / std::max(1, absm_side));
             const unsigned grid = (unsigned)std::min<uint32_t>(am.n_tiles, (uint32_t)(abs_cu_count() * per_cu));
-            (void)qcat_absmid_launch(hk.tpl[t].static_kernel, grid, q, &at);
+            (void)qcat_absmid_launch(sk, one ? 1 : 2, grid, q, &at);
         }
         MiddleAdapterArgs ma{kp, b->bases, b->offsets, c->mid_sorted, c->mid_len, c->mid_tables,
                              c->mid_bests + (size_t)t * slots, t, use_absm ? c->absm_need : nullptr};

@@ -225,15 +225,19 @@ def test_packed_detect_middle_matches_generic_kernel_and_oracle(monkeypatch, mod
     lib = native.HipLibrary.get().lib
     tiles = (ctypes.c_uint32 * 4)()
     assert lib.qcat_ctx_middle_bitslice_tiles(ctx().handle, tiles) == 0 and list(tiles) == [0, 0, 0, 0]
-    for rows_cap, on_path in ((None, True), ("10", False), ("3000", None)):
+    # ... and both kernel forms: templates of up to 46 columns walk a tile on one wave, the others (or everything with
+    # QCAT_HIP_MIDDLE_ABS_ONE_WAVE=0) on the two-wave pipeline
+    for rows_cap, on_path, one_wave in ((None, True, None), (None, True, "0"), ("10", False, None), ("3000", None, None), ("3000", None, "0")):
         with monkeypatch.context() as m:
             m.setenv("QCAT_HIP_MIDDLE_ABS_MIN", "1")
             if rows_cap:
                 m.setenv("QCAT_HIP_MIDDLE_ABS_ROWS", rows_cap)
+            if one_wave:
+                m.setenv("QCAT_HIP_MIDDLE_ABS_ONE_WAVE", one_wave)
             cnt_b = np.zeros(d.n_count_buckets, dtype=np.int64)
             recs_b = ctx().scan(kit_h, bases, offsets, counts=cnt_b)
             assert lib.qcat_ctx_middle_bitslice_tiles(ctx().handle, tiles) == 0
-        assert recs_b.tobytes() == o_recs.tobytes(), (rows_cap, list(tiles))
+        assert recs_b.tobytes() == o_recs.tobytes(), (rows_cap, one_wave, list(tiles))
         assert np.array_equal(cnt_b, o_cnt)
         assert tiles[1] >= 1 and tiles[3] >= tiles[1]
         if on_path is True:
