@@ -12,12 +12,17 @@
 static_assert(qabs::ABS_NI >= 14, "compile with -DQCAT_ABS_NI=14: interiors of up to 16 384 rows");
 
 // row counts, places and letter planes of the big tiles (k_absmid_codes, k_absmid_tiles, k_absmid_scan, k_absmid_planes); rspec zeroed by the caller
-extern "C" void qcat_absmid_prepare(void* stream, const void* args) {
+// win2 / wspec non-null: the M-ends' first windows and flags from the packed batch as well (k_absmid_windows instead of k_mid_windows)
+extern "C" void qcat_absmid_prepare(void* stream, const void* args, uint32_t* win2, uint8_t* wspec) {
     const qk::AbsMidArgs& a = *static_cast<const qk::AbsMidArgs*>(args);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned long long chunks = (a.n_bases + 15) / 16 + 1;
     hipLaunchKernelGGL(qk::k_absmid_codes, dim3((unsigned)std::min<unsigned long long>((chunks + 255) / 256, 1u << 20)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(qk::k_absmid_tiles, dim3(a.n_tiles), dim3(256), 0, s, a);
+    if (win2) {
+        const unsigned long long wthreads = (unsigned long long)a.slot_cap * 16;
+        hipLaunchKernelGGL(qk::k_absmid_windows, dim3((unsigned)((wthreads + 255) / 256)), dim3(256), 0, s, a, a.slot_cap, win2, wspec);
+    }
     hipLaunchKernelGGL(qk::k_absmid_scan, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(qk::k_absmid_planes, dim3(a.n_tiles, qk::ABSM_GY), dim3(256), 0, s, a);
 }

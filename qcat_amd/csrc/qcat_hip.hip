@@ -557,7 +557,7 @@ static bool middle_packed_ok(const DevKit& hk) {
 }
 
 // the bit-sliced interior adapter scan (kernels_abs_mid.inc, abs_mid_kernels.hip)
-extern "C" void qcat_absmid_prepare(void* stream, const void* args);
+extern "C" void qcat_absmid_prepare(void* stream, const void* args, uint32_t* win2, uint8_t* wspec);
 extern "C" int qcat_absmid_launch(int id, int waves, unsigned grid, void* stream, const void* args);
 
 // kit slots whose templates all have a two-stage bit-sliced plan (the built-in kits' single-template plans)
@@ -612,11 +612,14 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     // round 4: the interiors' first window at two bits per code, so that their whole-window barcode jobs -- nearly all of
     // them -- run on the bit-sliced barcode kernels (QCAT_HIP_MIDDLE_NO_BITSLICE=1: binary16 kernels as before)
     const bool mid_bs = getenv("QCAT_HIP_MIDDLE_NO_BITSLICE") == nullptr;
-    if (mid_bs) {
+    // (with the bit-sliced adapter scan below the windows come from its packed batch instead: k_absmid_windows.  k_mid_windows beside
+    //  the adapter kernels was measured and lost: those fill the register files, each of their waves walks ONE tile, and a wave that
+    //  starts late is the kernel's tail; beside the preparation chain -- kernels that wait for memory like itself -- it gained 0.02 ms)
+    auto launch_mid_windows = [&](hipStream_t q) {
         const uint64_t wthreads = (uint64_t)slots * 16;           // (sixteen lanes per slot; every slot's flag byte is stored, no fill)
-        hipLaunchKernelGGL(k_mid_windows, dim3((uint32_t)((wthreads + 255) / 256)), dim3(256), 0, st, b->bases, b->offsets, hk.max_align,
+        hipLaunchKernelGGL(k_mid_windows, dim3((uint32_t)((wthreads + 255) / 256)), dim3(256), 0, q, b->bases, b->offsets, hk.max_align,
                            c->mid_sorted, (uint32_t)slots, c->mid_win2, c->mid_wspec);
-    }
+    };
     sc->wspec = mid_bs ? c->mid_wspec : nullptr;          // (null: no letter flags, no bit-sliced classes)
     sc->win2 = mid_bs ? c->mid_win2 : nullptr;
     sc->win = c->win;                                     // (never read: the job regions come from win2, `lazy`)
@@ -663,13 +666,18 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             const char* pr = getenv("QCAT_HIP_ABS_PRIO");
             am.prio = pr ? atoi(pr) : 0;
             HIPCHK(hipMemsetAsync(am.cursor, 0, MAX_T * 4, st));
-            qcat_absmid_prepare(st, &am);
+            // the M-ends' first windows (k_mid_windows) come from the packed batch too: QCAT_HIP_MIDDLE_ABS_WINDOWS=0: from the reads, beside
+            const bool c2win = mid_bs && !(getenv("QCAT_HIP_MIDDLE_ABS_WINDOWS") && atoi(getenv("QCAT_HIP_MIDDLE_ABS_WINDOWS")) == 0);
+            fork_join(sc, st, (mid_bs && !c2win) ? 2 : 1, [&](int i, hipStream_t q) {
+                if (i == 0) qcat_absmid_prepare(q, &am, c2win ? c->mid_win2 : nullptr, c2win ? c->mid_wspec : nullptr); else launch_mid_windows(q);
+            });
             use_absm = true;
             c->absm_last_big = big; c->absm_last_128 = tiles;
         }
     }
     int absm_side = 0;                                             // templates on the bit-sliced path: launches side by side
     if (use_absm) for (int t = 0; t < hk.nt; ++t) if ((am.kit_mask >> hk.tpl[t].kit_slot) & 1u) ++absm_side;
+    if (mid_bs && !use_absm) launch_mid_windows(st);
     fork_join(sc, st, hk.nt, [&](int t, hipStream_t q) {
         if (use_absm && ((am.kit_mask >> hk.tpl[t].kit_slot) & 1u)) {
             AbsMidArgs at = am;
