@@ -13,11 +13,14 @@ static_assert(qabs::ABS_NI >= 14, "compile with -DQCAT_ABS_NI=14: interiors of u
 
 // row counts, places and letter planes of the big tiles (k_absmid_codes, k_absmid_tiles, k_absmid_scan, k_absmid_planes); rspec zeroed by the caller
 // win2 / wspec non-null: the M-ends' first windows and flags from the packed batch as well (k_absmid_windows instead of k_mid_windows)
-extern "C" void qcat_absmid_prepare(void* stream, const void* args, uint32_t* win2, uint8_t* wspec) {
+// what & 1: the packed batch (k_absmid_codes -- needs the reads only, so a scan starts it on a stream of its own beside the read
+// ends' kernels); what & 2: everything after it
+extern "C" void qcat_absmid_prepare(void* stream, const void* args, uint32_t* win2, uint8_t* wspec, int what) {
     const qk::AbsMidArgs& a = *static_cast<const qk::AbsMidArgs*>(args);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned long long chunks = (a.n_bases + 15) / 16 + 1;
-    hipLaunchKernelGGL(qk::k_absmid_codes, dim3((unsigned)std::min<unsigned long long>((chunks + 255) / 256, 1u << 20)), dim3(256), 0, s, a);
+    if (what & 1) hipLaunchKernelGGL(qk::k_absmid_codes, dim3((unsigned)std::min<unsigned long long>((chunks + 255) / 256, 1u << 20)), dim3(256), 0, s, a);
+    if (!(what & 2)) return;
     hipLaunchKernelGGL(qk::k_absmid_tiles, dim3(a.n_tiles), dim3(256), 0, s, a);
     if (win2) {
         const unsigned long long wthreads = (unsigned long long)a.slot_cap * 16;

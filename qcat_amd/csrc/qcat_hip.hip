@@ -438,6 +438,8 @@ struct qcat_ctx {
     uint32_t* absm_c2 = nullptr; size_t cap_absm_c2 = 0;          // the batch at two bits per base (with ABSM_C2_SLACK dwords on either side)
     uint8_t* absm_rspec = nullptr; size_t cap_absm_rspec = 0;
     uint64_t* absm_sinfo = nullptr; size_t cap_absm_sinfo = 0;
+    hipStream_t absm_stream = nullptr; hipEvent_t absm_go = nullptr, absm_done = nullptr;      // the packed batch beside the read ends' kernels
+    bool absm_codes_early = false;                                // this scan's k_absmid_codes is in flight on absm_stream
     uint32_t absm_last_big = 0, absm_last_128 = 0;                // big tiles / tiles of 128 slots of the latest scan on that path (0: not taken)
     uint32_t last_n_reads = 0;
     int last_buckets = 0;
@@ -509,6 +511,9 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     (void)hipFree(c->mid_win2); (void)hipFree(c->mid_wspec);
     (void)hipFree(c->absm_tiles); (void)hipFree(c->absm_need); (void)hipFree(c->absm_planes); (void)hipFree(c->absm_ns);
     (void)hipFree(c->absm_c2); (void)hipFree(c->absm_rspec); (void)hipFree(c->absm_sinfo);
+    if (c->absm_stream) (void)hipStreamDestroy(c->absm_stream);
+    if (c->absm_go) (void)hipEventDestroy(c->absm_go);
+    if (c->absm_done) (void)hipEventDestroy(c->absm_done);
     if (c->ev_ready) for (int r = 0; r < qcat_ctx::TIME_RING; ++r) for (int i = 0; i <= MAX_TIMED; ++i) (void)hipEventDestroy(c->evr[r][i]);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -557,7 +562,7 @@ static bool middle_packed_ok(const DevKit& hk) {
 }
 
 // the bit-sliced interior adapter scan (kernels_abs_mid.inc, abs_mid_kernels.hip)
-extern "C" void qcat_absmid_prepare(void* stream, const void* args, uint32_t* win2, uint8_t* wspec);
+extern "C" void qcat_absmid_prepare(void* stream, const void* args, uint32_t* win2, uint8_t* wspec, int what);
 extern "C" int qcat_absmid_launch(int id, int waves, unsigned grid, void* stream, const void* args);
 
 // kit slots whose templates all have a two-stage bit-sliced plan (the built-in kits' single-template plans)
@@ -572,12 +577,52 @@ static uint32_t absmid_kit_mask(const DevKit& hk) {
     return mask & ~bad;
 }
 
+// slots of the packed interior scan of n reads, and will its adapter scan run bit-sliced (kit mask != 0)?
+static size_t middle_slots(const DevKit& hk, uint32_t n) {
+    return ((size_t)2 * n + (size_t)hk.n_kit_slots * MID_CLASSES * PK_TILE + PK_TILE - 1) / PK_TILE * PK_TILE;
+}
+static uint32_t absmid_wanted(const DevKit& hk, uint32_t n) {
+    const char* amin = getenv("QCAT_HIP_MIDDLE_ABS_MIN");
+    const size_t min_slots = amin ? (size_t)atoll(amin) : (size_t)abs_cu_count() * 2048;
+    if (getenv("QCAT_HIP_MIDDLE_NO_ABS") || middle_slots(hk, n) < min_slots) return 0u;
+    return absmid_kit_mask(hk);
+}
+constexpr size_t ABSM_C2_SLACK_HOST = 1040;                                     // = ABSM_C2_SLACK (kernels_abs_mid.inc)
+
+// QCAT_HIP_MIDDLE_ABS_EARLY=1 (A/B switch, off by default): the batch at two bits per base (k_absmid_codes) at the start of a
+// --detect-middle scan on a stream of its own, beside the read ends' kernels -- it needs the reads only; middle_packed waits
+// for absm_done.  Measured at 1 M reads: the interior phase loses the kernel's 0.12 ms, k_pack_windows and the plane kernel of
+// the read ends -- bound by memory themselves -- gain 0.08 + 0.06 ms: 5.14 ms per step either way.
+static int absmid_codes_early(qcat_ctx* c, const DevKit& hk, const qcat_batch* b, uint32_t n) {
+    c->absm_codes_early = false;
+    if (!(getenv("QCAT_HIP_MIDDLE_ABS_EARLY") && atoi(getenv("QCAT_HIP_MIDDLE_ABS_EARLY")) == 1)) return 0;
+    if (!absmid_wanted(hk, n)) return 0;
+    int rc;
+    if (!c->absm_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->absm_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->absm_go, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->absm_done, hipEventDisableTiming));
+    }
+    if ((rc = grow(&c->absm_c2, &c->cap_absm_c2, (size_t)(b->n_bases / 16) + 4 + 2 * ABSM_C2_SLACK_HOST))) return rc;
+    if ((rc = grow(&c->absm_rspec, &c->cap_absm_rspec, (size_t)n + 1))) return rc;
+    AbsMidArgs am{};
+    am.bases = b->bases; am.offsets = b->offsets; am.max_align = hk.max_align; am.n_bases = b->n_bases; am.n_reads = n;
+    am.c2 = c->absm_c2 + ABSM_C2_SLACK_HOST; am.rspec = c->absm_rspec;
+    HIPCHK(hipEventRecord(c->absm_go, c->stream));                 // (after whatever the stream holds: the previous scan's readers of c2)
+    HIPCHK(hipStreamWaitEvent(c->absm_stream, c->absm_go, 0));
+    HIPCHK(hipMemsetAsync(c->absm_rspec, 0, (size_t)n + 1, c->absm_stream));
+    qcat_absmid_prepare(c->absm_stream, &am, nullptr, nullptr, 1);
+    HIPCHK(hipEventRecord(c->absm_done, c->absm_stream));
+    c->absm_codes_early = true;
+    return 0;
+}
+
 // the interior scan of every called read on the packed kernels (kernels_middle.inc); leaves
 // c->mid_generic[r] = 1 for reads it could not take (interior longer than the length classes)
 static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_batch* b, uint32_t n) {
     hipStream_t st = c->stream;
     int rc;
-    const size_t slots = ((size_t)2 * n + (size_t)hk.n_kit_slots * MID_CLASSES * PK_TILE + PK_TILE - 1) / PK_TILE * PK_TILE;
+    const size_t slots = middle_slots(hk, n);
     if (slots >= (1ull << 31)) return set_err(QCAT_ERR_UNSUPPORTED, "batch too large for the packed interior scan");
     if (!c->mid_tables) HIPCHK(hipMalloc((void**)&c->mid_tables, sizeof(MidTables)));
     if ((rc = grow(&c->mid_generic, &c->cap_mid_generic, (size_t)n))) return rc;
@@ -634,10 +679,8 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     bool use_absm = false;
     c->absm_last_big = 0; c->absm_last_128 = 0;
     {
-        const char* amin = getenv("QCAT_HIP_MIDDLE_ABS_MIN");
-        const size_t min_slots = amin ? (size_t)atoll(amin) : (size_t)abs_cu_count() * 2048;
-        const uint32_t kmask = getenv("QCAT_HIP_MIDDLE_NO_ABS") ? 0u : absmid_kit_mask(hk);
-        if (kmask && slots >= min_slots) {
+        const uint32_t kmask = absmid_wanted(hk, n);
+        if (kmask) {
             const uint32_t big = (uint32_t)((slots + 2047) / 2048);
             // rows of all big tiles together: every tile as long as its longest interior -- the mean of the interiors plus
             // the width of the length classes a tile spans; a tile beyond the room falls back to the binary16 kernel
@@ -649,9 +692,13 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             if ((rc = grow(&c->absm_need, &c->cap_absm_need, (size_t)tiles + 16))) return rc;
             if ((rc = grow(&c->absm_planes, &c->cap_absm_planes, rows * 64))) return rc;
             if ((rc = grow(&c->absm_ns, &c->cap_absm_ns, rows * 64))) return rc;
-            constexpr size_t C2_SLACK = 1040;                                   // = ABSM_C2_SLACK (kernels_abs_mid.inc)
-            if ((rc = grow(&c->absm_c2, &c->cap_absm_c2, (size_t)(b->n_bases / 16) + 4 + 2 * C2_SLACK))) return rc;
-            if ((rc = grow(&c->absm_rspec, &c->cap_absm_rspec, (size_t)n + 1))) return rc;
+            constexpr size_t C2_SLACK = ABSM_C2_SLACK_HOST;
+            const bool early = c->absm_codes_early;                             // (absmid_codes_early: the packed batch is on its way)
+            c->absm_codes_early = false;
+            if (!early) {
+                if ((rc = grow(&c->absm_c2, &c->cap_absm_c2, (size_t)(b->n_bases / 16) + 4 + 2 * C2_SLACK))) return rc;
+                if ((rc = grow(&c->absm_rspec, &c->cap_absm_rspec, (size_t)n + 1))) return rc;
+            }
             if ((rc = grow(&c->absm_sinfo, &c->cap_absm_sinfo, slots))) return rc;
             uint32_t* w = c->absm_tiles;
             am.bases = b->bases; am.offsets = b->offsets; am.msorted = c->mid_sorted; am.mlen = c->mid_len; am.mt = c->mid_tables;
@@ -660,7 +707,8 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             am.nonempty = w + 4 * (size_t)big; am.invalid = w + 4 * (size_t)big + 64 * (size_t)big;
             am.cursor = w + (size_t)big * (4 + 128);
             am.c2 = c->absm_c2 + C2_SLACK; am.rspec = c->absm_rspec; am.sinfo = c->absm_sinfo; am.n_bases = b->n_bases; am.n_reads = n;
-            HIPCHK(hipMemsetAsync(c->absm_rspec, 0, (size_t)n + 1, st));
+            if (early) HIPCHK(hipStreamWaitEvent(st, c->absm_done, 0));
+            else HIPCHK(hipMemsetAsync(c->absm_rspec, 0, (size_t)n + 1, st));
             am.need128 = c->absm_need; am.planes = c->absm_planes; am.ns = c->absm_ns; am.row_cap = (uint32_t)rows;
             am.bests = c->mid_bests; am.tpl = -1; am.den = 0; am.kit_slot = -1;
             const char* pr = getenv("QCAT_HIP_ABS_PRIO");
@@ -669,7 +717,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             // the M-ends' first windows (k_mid_windows) come from the packed batch too: QCAT_HIP_MIDDLE_ABS_WINDOWS=0: from the reads, beside
             const bool c2win = mid_bs && !(getenv("QCAT_HIP_MIDDLE_ABS_WINDOWS") && atoi(getenv("QCAT_HIP_MIDDLE_ABS_WINDOWS")) == 0);
             fork_join(sc, st, (mid_bs && !c2win) ? 2 : 1, [&](int i, hipStream_t q) {
-                if (i == 0) qcat_absmid_prepare(q, &am, c2win ? c->mid_win2 : nullptr, c2win ? c->mid_wspec : nullptr); else launch_mid_windows(q);
+                if (i == 0) qcat_absmid_prepare(q, &am, c2win ? c->mid_win2 : nullptr, c2win ? c->mid_wspec : nullptr, early ? 2 : 3); else launch_mid_windows(q);
             });
             use_absm = true;
             c->absm_last_big = big; c->absm_last_128 = tiles;
@@ -762,6 +810,8 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     if (!keep_counts) HIPCHK(packed_fill(c->counts, 0, (size_t)hk.n_buckets * 8, c->stream));
     if (n == 0) { HIPCHK(packed_fill_flush(c->stream)); return 0; }
     if (c->timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));   // (an empty batch returned above: its slot holds no marks)
+    c->absm_codes_early = false;
+    if (hk.scan_middle && !adapter_only && use_packed && middle_packed_ok(hk) && (rc = absmid_codes_early(c, hk, b, n))) return rc;
 
     KitPtrs kp{kd->kit, kd->codes, kd->ids, kd->tables};
     g_jit = kd;

@@ -7,7 +7,7 @@ B="timeout 600 python bench.py --no-host-inclusive --cpu-seconds 2"
 for i in 1 2; do
   $B --workload middle --steps 10 --warmup 2 > $out/mid_abs_$i.json 2>$out/mid_abs_$i.err
   QCAT_HIP_MIDDLE_NO_ABS=1 $B --workload middle --steps 10 --warmup 2 > $out/mid_f16_$i.json 2>$out/mid_f16_$i.err
-  QCAT_HIP_MIDDLE_ABS_WINDOWS=0 $B --workload middle --steps 10 --warmup 2 > $out/mid_abs_w0_$i.json 2>$out/mid_abs_w0_$i.err
+  QCAT_HIP_MIDDLE_ABS_EARLY=1 $B --workload middle --steps 10 --warmup 2 > $out/mid_abs_e1_$i.json 2>$out/mid_abs_e1_$i.err
 done
 tail -3 $out/mid_abs_1.err
 python - <<'PY'
