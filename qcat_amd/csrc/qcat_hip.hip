@@ -437,7 +437,7 @@ struct qcat_ctx {
     uint32_t* absm_ns = nullptr; size_t cap_absm_ns = 0;
     uint32_t* absm_c2 = nullptr; size_t cap_absm_c2 = 0;          // the batch at two bits per base (with ABSM_C2_SLACK dwords on either side)
     uint8_t* absm_rspec = nullptr; size_t cap_absm_rspec = 0;
-    uint64_t* absm_sinfo = nullptr; size_t cap_absm_sinfo = 0;
+    uint4* absm_sinfo = nullptr; size_t cap_absm_sinfo = 0;      // per slot: position / strand, length, special flag
     hipStream_t absm_stream = nullptr; hipEvent_t absm_go = nullptr, absm_done = nullptr;      // the packed batch beside the read ends' kernels
     bool absm_codes_early = false;                                // this scan's k_absmid_codes is in flight on absm_stream
     uint32_t absm_last_big = 0, absm_last_128 = 0;                // big tiles / tiles of 128 slots of the latest scan on that path (0: not taken)
