@@ -1,17 +1,14 @@
 #!/bin/bash
-# round 4, last validation of the final tree: the whole GPU suite, smoke(), the default bench line, config 2 / middle / api4000 once more
-cd ${GRAFT_REPO_ROOT:-.}
-out=gpurun_out/r04_final_d; mkdir -p $out
-(time timeout 2400 python -m pytest tests -x -q -m gpu) > $out/tests_full.log 2>&1; echo "pytest rc=$?"; tail -5 $out/tests_full.log
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $out/smoke.log
-timeout 600 python bench.py > $out/bench_default.json 2>$out/bench_default.err
-for wl in config2 middle api4000 dual; do timeout 600 python bench.py --workload $wl > $out/bench_$wl.json 2>$out/bench_$wl.err; done
-python - <<'PY'
-import json, glob, os
-for f in sorted(glob.glob('gpurun_out/r04_final_d/*.json')):
-    try:
-        d = json.loads(open(f).read().strip().splitlines()[-1])
-    except Exception as e:
-        print(os.path.basename(f), 'ERR', e); continue
-    print(os.path.basename(f), round(d['value'] / 1e6, 3), d['ms_per_step'], d.get('split_ms_per_call'), (d.get('roofline') or {}).get('frac'), (d.get('cpu_baseline') or {}).get('value'), (d.get('parity') or {}))
-PY
+# round 4, final tree: fuzz sweep of the bit-sliced interior adapter scan, rocprofv3 evidence for --detect-middle, bench lines, full GPU suite, smoke
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r04d
+(timeout 1200 python tools/fuzz_middle.py 0 48) > gpurun_out/r04d/fuzz_middle_0_47.txt 2>&1; tail -2 gpurun_out/r04d/fuzz_middle_0_47.txt
+bash tools/profile.sh r04_absmid middle --steps 5 --warmup 1 > gpurun_out/r04d/prof_middle.log 2>&1
+cd $GRAFT_REPO_ROOT
+for wl in middle; do
+  timeout 900 python bench.py --workload $wl > gpurun_out/r04d/bench_$wl.json 2> gpurun_out/r04d/bench_$wl.err
+  python -c "
+import json; d=json.loads(open('gpurun_out/r04d/bench_$wl.json').read().strip().splitlines()[-1]); print('$wl', d['value'], d['ms_per_step'], (d.get('roofline') or {}).get('kernels_avg_ms'))" 2>&1 | cut -c1-400
+done
+bash tools/r04_absmid.sh 2>&1 | tail -7 | cut -c1-60
+bash tools/gpu_final_validation.sh
