@@ -583,7 +583,9 @@ static size_t middle_slots(const DevKit& hk, uint32_t n) {
 }
 static uint32_t absmid_wanted(const DevKit& hk, uint32_t n) {
     const char* amin = getenv("QCAT_HIP_MIDDLE_ABS_MIN");
-    const size_t min_slots = amin ? (size_t)atoll(amin) : (size_t)abs_cu_count() * 2048;
+    // from 1.25 big tiles of 2048 slots per CU (330 k reads on 256 CUs): below that the binary16 kernel's 3 us per thousand interiors
+    // beat a tile's sequential walk (tools/r04_absmid_sizes.sh, profiles/r04_ab_absmid_sizes.txt)
+    const size_t min_slots = amin ? (size_t)atoll(amin) : (size_t)abs_cu_count() * 2048 * 5 / 4;
     if (getenv("QCAT_HIP_MIDDLE_NO_ABS") || middle_slots(hk, n) < min_slots) return 0u;
     return absmid_kit_mask(hk);
 }
@@ -734,11 +736,14 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             // persistent two-wave workgroups: four per CU (two waves per SIMD) shared by the templates that run side by side --
             // two launches of four per CU each do not fit the register file together, and the second one then runs after
             // the first (1.2 + 0.6 ms at 1 M reads against ~1.0 ms side by side).  QCAT_HIP_MIDDLE_ABS_WGS=<per CU and launch>
-            // A template of up to 46 columns walks a tile on ONE wave (k_adapter_mid1: eight per CU); QCAT_HIP_MIDDLE_ABS_ONE_WAVE=0: pipeline.
+            // A template of up to 46 columns walks a tile on ONE wave (k_adapter_mid1: eight per CU); QCAT_HIP_MIDDLE_ABS_ONE_WAVE=0 / 1: pipeline / one wave whatever the size.
             const char* wg = getenv("QCAT_HIP_MIDDLE_ABS_WGS");
             const char* ow = getenv("QCAT_HIP_MIDDLE_ABS_ONE_WAVE");
             const int sk = hk.tpl[t].static_kernel;
-            const bool one = !(ow && atoi(ow) == 0) && qcat_absmid_launch(sk, 1, 0, nullptr, nullptr) != 0;
+            // one wave per tile from 2.75 big tiles per CU (720 k reads): with fewer tiles than wave slots a tile's walk is the kernel,
+            // and the pipeline's two waves halve it (400 k reads: interior phase 1.95 against 2.29 ms; 800 k: 2.96 against 2.87)
+            const bool big_enough = slots >= (size_t)abs_cu_count() * 2048 * 11 / 4;
+            const bool one = (ow ? atoi(ow) != 0 : big_enough) && qcat_absmid_launch(sk, 1, 0, nullptr, nullptr) != 0;
             const int per_cu = wg ? atoi(wg) : std::max(1, (one ? 8 : 4) / std::max(1, absm_side));
             const unsigned grid = (unsigned)std::min<uint32_t>(am.n_tiles, (uint32_t)(abs_cu_count() * per_cu));
             (void)qcat_absmid_launch(sk, one ? 1 : 2, grid, q, &at);

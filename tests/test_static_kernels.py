@@ -225,9 +225,9 @@ def test_packed_detect_middle_matches_generic_kernel_and_oracle(monkeypatch, mod
     lib = native.HipLibrary.get().lib
     tiles = (ctypes.c_uint32 * 4)()
     assert lib.qcat_ctx_middle_bitslice_tiles(ctx().handle, tiles) == 0 and list(tiles) == [0, 0, 0, 0]
-    # ... and both kernel forms: templates of up to 46 columns walk a tile on one wave, the others (or everything with
-    # QCAT_HIP_MIDDLE_ABS_ONE_WAVE=0) on the two-wave pipeline
-    for rows_cap, on_path, one_wave in ((None, True, None), (None, True, "0"), ("10", False, None), ("3000", None, None), ("3000", None, "0")):
+    # ... and both kernel forms: templates of up to 46 columns walk a tile on one wave (big batches, or QCAT_HIP_MIDDLE_ABS_ONE_WAVE=1),
+    # the others (and medium batches, or everything with QCAT_HIP_MIDDLE_ABS_ONE_WAVE=0) on the two-wave pipeline
+    for rows_cap, on_path, one_wave in ((None, True, "1"), (None, True, "0"), ("10", False, None), ("3000", None, "1"), ("3000", None, "0")):
         with monkeypatch.context() as m:
             m.setenv("QCAT_HIP_MIDDLE_ABS_MIN", "1")
             if rows_cap:
