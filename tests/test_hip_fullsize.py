@@ -294,3 +294,31 @@ def test_config5_dual_one_million_reads(which, tmp_path):
         assert set(np.unique(recs["exit_status"])) <= {0, 1, 1002}
     finally:
         r.close()
+
+
+def test_detect_middle_one_million_reads_across_interior_paths(monkeypatch):
+    """--detect-middle at the size of its bench workload: every record of the batch is the same with the interior adapter scan
+    bit-sliced on one wave per tile (the default at this size, kernels_abs_mid.inc), on the two-wave pipeline and on the
+    binary16 kernel (k_adapter_middle: another algorithm, another data layout); the tiles really ran bit-sliced; a sample
+    goes through the oracle (detect_barcode's interior scan, qcat/scanner_base.py:479-519, :593-595)."""
+    det = scanner.factory(kit="NBD103/NBD104", scan_middle_adapter=True)
+    r = Resident(det, native.ENDS_BOTH, 1000000, 20260930, 0.08)
+    try:
+        assert r.desc.scan_middle
+        recs, cnt = r.scan()
+        tiles = (C.c_uint32 * 4)()
+        r.hip.check(r.lib.qcat_ctx_middle_bitslice_tiles(r.ctx.handle, tiles))
+        assert tiles[0] >= 800 and tiles[0] >= tiles[1] - 8 and tiles[2] <= tiles[3] // 50, list(tiles)
+        assert cnt[:13].sum() == r.n
+        for name, value in (("QCAT_HIP_MIDDLE_ABS_ONE_WAVE", "0"), ("QCAT_HIP_MIDDLE_NO_ABS", "1")):
+            monkeypatch.setenv(name, value)
+            other, cnt_o = r.scan()
+            r.hip.check(r.lib.qcat_ctx_middle_bitslice_tiles(r.ctx.handle, tiles))
+            monkeypatch.delenv(name)
+            assert (tiles[0] == 0) == (name == "QCAT_HIP_MIDDLE_NO_ABS"), (name, list(tiles))
+            diff = np.flatnonzero(other != recs)
+            assert diff.size == 0, "%s=%s: %d records differ, first at read %d" % (name, value, diff.size, diff[0])
+            assert np.array_equal(cnt, cnt_o)
+        check_sample_against_oracle(r, recs, 2000, np.random.default_rng(5))
+    finally:
+        r.close()
