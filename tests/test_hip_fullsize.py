@@ -308,7 +308,8 @@ def test_detect_middle_one_million_reads_across_interior_paths(monkeypatch):
         recs, cnt = r.scan()
         tiles = (C.c_uint32 * 4)()
         r.hip.check(r.lib.qcat_ctx_middle_bitslice_tiles(r.ctx.handle, tiles))
-        assert tiles[0] >= 800 and tiles[0] >= tiles[1] - 8 and tiles[2] <= tiles[3] // 50, list(tiles)
+        # (the slots have room for every length class of every kit slot: the big tiles beyond the last M-end are empty)
+        assert 800 <= tiles[0] <= tiles[1] and tiles[2] <= tiles[3] // 50, list(tiles)
         assert cnt[:13].sum() == r.n
         for name, value in (("QCAT_HIP_MIDDLE_ABS_ONE_WAVE", "0"), ("QCAT_HIP_MIDDLE_NO_ABS", "1")):
             monkeypatch.setenv(name, value)
