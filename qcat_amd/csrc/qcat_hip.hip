@@ -713,8 +713,10 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             else HIPCHK(hipMemsetAsync(c->absm_rspec, 0, (size_t)n + 1, st));
             am.need128 = c->absm_need; am.planes = c->absm_planes; am.ns = c->absm_ns; am.row_cap = (uint32_t)rows;
             am.bests = c->mid_bests; am.tpl = -1; am.den = 0; am.kit_slot = -1;
-            const char* pr = getenv("QCAT_HIP_ABS_PRIO");
-            am.prio = pr ? atoi(pr) : 0;
+            // issue priority of the row loops rotated every two rows by workgroup parity (abs_setprio; two waves of different
+            // launches share a SIMD): 4.79 against 4.91 ms per step at 1 M reads (tools/r04_absmid_prio.sh); QCAT_HIP_MIDDLE_ABS_PRIO
+            const char* pr = getenv("QCAT_HIP_MIDDLE_ABS_PRIO") ? getenv("QCAT_HIP_MIDDLE_ABS_PRIO") : getenv("QCAT_HIP_ABS_PRIO");
+            am.prio = pr ? atoi(pr) : 2;
             HIPCHK(hipMemsetAsync(am.cursor, 0, MAX_T * 4, st));
             // the M-ends' first windows (k_mid_windows) come from the packed batch too: QCAT_HIP_MIDDLE_ABS_WINDOWS=0: from the reads, beside
             const bool c2win = mid_bs && !(getenv("QCAT_HIP_MIDDLE_ABS_WINDOWS") && atoi(getenv("QCAT_HIP_MIDDLE_ABS_WINDOWS")) == 0);
