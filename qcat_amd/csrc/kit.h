@@ -60,13 +60,21 @@ struct DevSet {
     int32_t hot_len;            // the region length almost every job of this set has: barcode + 2 * extension + 1
     int32_t bs_pre;             // bit-sliced kernels: leading columns every barcode of the set shares (0, 4, 8 or 11 context letters)
     int32_t bs_rev;             // ... rows and target letters run backwards (the downstream context is the longer one)
+    int32_t bs_post;            // ... trailing columns (11 / 8 / 7 / 6 / 4 / 0 letters of the other context) that every barcode shares as well:
+                                // computed once per super-tile by the reversed DP (bs_core.h, round 5); own columns = tlen - bs_pre - bs_post
     int32_t bs_kernel;          // bit-sliced kernel with this set's letters compiled in (static_generated.inc / run-time code), -1: none
     int32_t bs_case_off;        // ids blob: per barcode its case of that kernel
     int32_t len_off;            // simple mode, barcodes of unequal length: ids blob, per barcode (length, min_raw_pass, min_raw_conflict);
                                 // -1: every barcode has blen letters (the set's own tlen / thresholds apply)
 };
 
-constexpr int BS_C_MIN = 20, BS_C_MAX = 48;    // own columns (tlen - bs_pre) the bit-sliced kernels are instantiated for
+constexpr int BS_C_MIN = 20, BS_C_MAX = 48;    // own columns (tlen - bs_pre - bs_post) the bit-sliced kernels are instantiated for
+// trailing columns of a set on the bit-sliced kernels (the rule is restated in tools/gen_static_kernels.py and qcat_amd/jit.py)
+inline int bs_post_of(int trail, int tlen, int pre) {
+    const int posts[5] = {11, 8, 7, 6, 4};
+    for (int q : posts) if (q <= trail && tlen - pre - q >= BS_C_MIN) return q;
+    return 0;
+}
 
 // work units of a static-letter barcode group per tile: chunks of quads first, then chunks of the pairs left over
 inline int static_units(int n_quads, int n_pairs, int chunk_b) {

@@ -280,14 +280,15 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
             # bit-sliced rows with the letters compiled in (kernels_bitslice.inc): case = barcode index
             shape = _bs_shape(len(up), len(dn), m) if len(targets) <= 128 else None
             if shape:
-                rev, pre, own = shape
+                rev, pre, own, post = shape
                 s1, s0 = _bs_shared_words(targets[0], rev, pre)
-                parts.append("struct QBSJ_%d {\n    static constexpr int C = %d, KERNEL = QCAT_JIT_BASE + %d, PRE = %d;\n"
-                             "    static constexpr unsigned S1 = 0x%Xu, S0 = 0x%Xu;\n"
+                t1, t0 = _bs_trailing_words(targets[0], rev, post)
+                parts.append("struct QBSJ_%d {\n    static constexpr int C = %d, KERNEL = QCAT_JIT_BASE + %d, PRE = %d, POST = %d;\n"
+                             "    static constexpr unsigned S1 = 0x%Xu, S0 = 0x%Xu, T1 = 0x%Xu, T0 = 0x%Xu;\n"
                              "    static __device__ __forceinline__ void rows(int kase, const BsRowArgs& ra, "
-                             "u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n" % (g, own, g, pre, s1, s0))
+                             "u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_ND]) {\n        switch (kase) {\n" % (g, own, g, pre, post, s1, s0, t1, t0))
                 for b, tg in enumerate(targets):
-                    w1, w0 = _bs_words(tg, rev, pre)
+                    w1, w0 = _bs_words(tg, rev, pre, own)
                     parts.append("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(ra, h1, h0, f); break;\n" % (b, w1, w0))
                 parts.append("        default: break;\n        }\n    }\n};\n")
                 entry.append('extern "C" __global__ void __launch_bounds__(qk::BS_WAVES * 64) '
@@ -305,23 +306,39 @@ def generate(descriptor, skip_templates=(), skip_groups=()):
 BS_C_MIN, BS_C_MAX = 20, 48          # kit.h
 
 
+BS_POSTS = (11, 8, 7, 6, 4)          # kit.h: bs_post_of
+
+
 def _bs_shape(uplen, downlen, m):
-    """(reversed, shared columns, own columns) of a set on the bit-sliced kernels, or None -- the rule of
-    kit_prepare.inc: the longer context leads, 11 / 8 / 4 / 0 of its columns are shared"""
+    """(reversed, shared columns, own columns, trailing columns) of a set on the bit-sliced kernels, or None -- the rule of
+    kit_prepare.inc: the longer context leads, 11 / 8 / 4 / 0 of its columns are shared; 11 / 8 / 7 / 6 / 4 / 0 columns of the
+    other context go through the reversed DP (csrc/bs_core.h)"""
     rev = downlen > uplen
-    lead = downlen if rev else uplen
+    lead, trail = (downlen, uplen) if rev else (uplen, downlen)
     pre = 11 if lead >= 11 else (8 if lead >= 8 else (4 if lead >= 4 else 0))
-    own = m - pre
+    post = next((q for q in BS_POSTS if q <= trail and m - pre - q >= BS_C_MIN), 0)
+    own = m - pre - post
     if not (BS_C_MIN <= own <= BS_C_MAX and m <= 64):
         return None
-    return rev, pre, own
+    return rev, pre, own, post
 
 
-def _bs_words(codes, rev, pre):
+def _bs_words(codes, rev, pre, own):
     """letter bit words of the own columns in the order the kernel walks them (bit j = own column j)"""
     t = codes[::-1] if rev else codes
     w1 = w0 = 0
-    for j, c in enumerate(t[pre:]):
+    for j, c in enumerate(t[pre:pre + own]):
+        w1 |= ((c >> 1) & 1) << j
+        w0 |= (c & 1) << j
+    return w1, w0
+
+
+def _bs_trailing_words(codes, rev, post):
+    """letter bit words of the trailing columns in the order the reversed DP walks them (bit j = the last column but j)"""
+    t = codes[::-1] if rev else codes
+    w1 = w0 = 0
+    for j in range(post):
+        c = t[len(t) - 1 - j]
         w1 |= ((c >> 1) & 1) << j
         w0 |= (c & 1) << j
     return w1, w0

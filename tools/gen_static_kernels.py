@@ -24,6 +24,7 @@ OUT = os.path.join(ROOT, "qcat_amd", "csrc", "static_generated.inc")
 QUAD_MIN_TARGETS = 48       # families this large also get four-target chains (the big sets dominate the run time)
 BS_MIN_TARGETS = 12         # families this large get bit-sliced row loops with the letters compiled in (kernels_bitslice.inc)
 BS_C_MIN, BS_C_MAX = 20, 48 # kit.h
+BS_POSTS = (11, 8, 7, 6, 4) # trailing columns the reversed DP takes (kit_prepare.inc, the instantiations of kernels_bitslice.inc)
 BS_PARTS = 6                # translation units the bit-sliced static-letter kernels are split over (__graft_entry__.build)
 BS_OUT = os.path.join(ROOT, "qcat_amd", "csrc", "bs_static_generated.inc")
 CODE = {"A": 0, "T": 1, "G": 2, "C": 3}
@@ -57,23 +58,38 @@ def chain(letters, code):
 
 
 def bs_shape(uplen, downlen, m):
-    """(reversed, shared columns, own columns) of a target family on the bit-sliced kernels, or None: the rule of
-    kit_prepare.inc (the longer context leads; 11 / 8 / 4 / 0 of its columns are shared)"""
+    """(reversed, shared columns, own columns, trailing columns) of a target family on the bit-sliced kernels, or None: the
+    rule of kit_prepare.inc (the longer context leads; 11 / 8 / 4 / 0 of its columns are shared; round 5: the other context's
+    columns -- 11 / 8 / 7 / 6 / 4 / 0 of them, as long as BS_C_MIN own columns remain -- are computed once per super-tile as well, by
+    the reversed DP of bs_core.h)"""
     rev = downlen > uplen
-    lead = downlen if rev else uplen
+    lead, trail = (downlen, uplen) if rev else (uplen, downlen)
     pre = 11 if lead >= 11 else (8 if lead >= 8 else (4 if lead >= 4 else 0))
-    own = m - pre
+    post = next((q for q in BS_POSTS if q <= trail and m - pre - q >= BS_C_MIN), 0)
+    own = m - pre - post
     if not (BS_C_MIN <= own <= BS_C_MAX and m <= 64):
         return None
-    return rev, pre, own
+    return rev, pre, own, post
 
 
-def bs_words(target, rev, pre, code):
+def bs_words(target, rev, pre, code, own=None):
     """letter bit words of the own columns in the order the kernel walks them (bit j = own column j)"""
     t = target[::-1] if rev else target
     w1 = w0 = 0
-    for j, ch in enumerate(t[pre:]):
+    for j, ch in enumerate(t[pre:pre + own] if own is not None else t[pre:]):
         c = code[ch]
+        w1 |= ((c >> 1) & 1) << j
+        w0 |= (c & 1) << j
+    return w1, w0
+
+
+def bs_trailing_words(target, rev, post, code):
+    """letter bit words of the trailing context's columns in the order the REVERSED DP walks them (bit j = its column j =
+    the target's last column but j, in walk order)"""
+    t = target[::-1] if rev else target
+    w1 = w0 = 0
+    for j in range(post):
+        c = code[t[len(t) - 1 - j]]
         w1 |= ((c >> 1) & 1) << j
         w0 |= (c & 1) << j
     return w1, w0
@@ -234,20 +250,23 @@ def render():
             shape = bs_shape(len(up), len(dn), m) if len(targets) >= BS_MIN_TARGETS else None
             bs_fams.append((kid, len(up), len(dn), shape is not None))
             if shape:
-                rev, pre, own = shape
+                rev, pre, own, post = shape
                 bh = _Buf()
-                bh.write("struct QBS_%d {      // %s + barcode + %s: %s, %d shared + %d own columns, %d targets\n"
-                         % (kid, up, dn, "reversed" if rev else "forward", pre, own, len(targets)))
+                bh.write("struct QBS_%d {      // %s + barcode + %s: %s, %d shared + %d own + %d trailing columns, %d targets\n"
+                         % (kid, up, dn, "reversed" if rev else "forward", pre, own, post, len(targets)))
                 s1, s0 = bs_shared_words(targets[0], rev, pre, CODE)
-                bh.write("    static constexpr int C = %d, KERNEL = %d, PRE = %d;\n    static constexpr unsigned S1 = 0x%Xu, S0 = 0x%Xu;      // letters of the shared columns\n"
-                         % (own, kid, pre, s1, s0))
+                t1, t0 = bs_trailing_words(targets[0], rev, post, CODE)
+                bh.write("    static constexpr int C = %d, KERNEL = %d, PRE = %d, POST = %d;\n"
+                         "    static constexpr unsigned S1 = 0x%Xu, S0 = 0x%Xu;      // letters of the shared columns\n"
+                         "    static constexpr unsigned T1 = 0x%Xu, T0 = 0x%Xu;      // letters of the trailing columns, last column first\n"
+                         % (own, kid, pre, post, s1, s0, t1, t0))
                 bh.write("    static __device__ __forceinline__ void rows(int kase, const BsRowArgs& ra, "
-                         "u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_NF]) {\n        switch (kase) {\n")
+                         "u32 (&h1)[C], u32 (&h0)[C], u32 (&f)[BS_ND]) {\n        switch (kase) {\n")
                 for pr, (ta, tb, up_) in enumerate(pairs):
                     for half, t in ((0, ta), (1, tb)):
                         if half == 1 and tb == ta:
                             continue
-                        w1, w0 = bs_words(t, rev, pre, CODE)
+                        w1, w0 = bs_words(t, rev, pre, CODE, own)
                         bh.write("        case %d: bs_rows_static<C, 0x%XULL, 0x%XULL>(ra, h1, h0, f); break;\n"
                                  % (2 * pr + half, w1, w0))
                 bh.write("        default: break;\n        }\n    }\n};\n")
