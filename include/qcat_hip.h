@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QCAT_ABI_VERSION 4
+#define QCAT_ABI_VERSION 5
 
 /* Base code space shared by host and device (qcat_amd/codes.py): parasail's mapper sends the
  * alphabet letters (either case) to their index and everything else to the '*' row
@@ -430,17 +430,56 @@ typedef struct qcat_demux_opts {
     const char* const* const* bc_name;
     const int32_t* const* bc_id;
     const int32_t* const* bc2_id;
+    /* ABI 5 */
+    int32_t filter_barcodes;   /* --filter-barcodes (cli.py:165-171 -> scanner_base.py:690-712, :730-731): per batch of batch_size reads the
+                                * calls are counted by Barcode.id ("0": no barcode), and a call whose barcode has at most
+                                * int(0.05 * the largest count) reads becomes the empty result (no barcode, no adapter, exit status 1,
+                                * trims 0).  0 when the driver runs without batches (--no-batch calls detect_barcode, cli.py:504-509) */
+    int32_t stream_reader;     /* qcat_fastq_demux_stream: how a segment's bytes are fetched -- 0: the default, 1: pread() into reused buffers,
+                                * 2: a mapped window of the file per segment */
+    uint64_t segment_bytes;    /* qcat_fastq_demux_stream: bytes of the file per segment (0: 256 MiB) */
 } qcat_demux_opts;
 typedef struct qcat_demux_stats {
     uint64_t n_reads, n_skipped, file_bytes;
     double parse_s, scan_s, write_s;       /* record splitting (qcat_fastq_open); upload + kernels + download; formatting + write() */
     double total_s;                        /* the call: the writers run beside the scan, so total_s < scan_s + write_s */
+    /* ABI 5, qcat_fastq_demux_stream */
+    uint64_t next_offset;                  /* file offset behind the last read that was handled (the file size unless `incomplete`) */
+    int32_t incomplete;                    /* 1: the loop ended in front of a segment holding a record that is not plain (see there) */
+    int32_t segments;
 } qcat_demux_stats;
 /* scans every read of the file with `kit` (QCAT_ENDS_BOTH) and writes the outputs; recs[r] / skipped[r] (n_reads entries
  * each, caller-owned) receive the record of read r and whether the minimum-length filter dropped it.
  * QCAT_ERR_UNSUPPORTED: simple mode, or kit_auto with a kit whose adapter pass cannot be resumed per kit. */
 int  qcat_fastq_demux(qcat_fastq* f, qcat_ctx* ctx, const qcat_kit* kit, const qcat_demux_opts* opts,
                       qcat_result* recs, uint8_t* skipped, qcat_demux_stats* stats);
+
+/* ---- the same loop over a file of any size in bounded host memory (ABI 5) ----
+ * replaces: the per-file loop of the reference driver as it STREAMS -- iter_fastx yields one batch at a time
+ * (qcat/cli.py:235-306), the loop scans and writes it (:500-552) and keeps nothing but the two histograms (:366-383,
+ * :531-534).  The file is taken in segments (opts->segment_bytes) through a three-stage pipeline: segment k + 1 is read
+ * (pread into a reused buffer) and split into records while segment k is scanned and segment k - 1 is written; a segment is
+ * cut at a whole batch of batch_size reads counted from the start of the file whenever batches matter (kit_auto,
+ * filter_barcodes).  Kits created with scan_middle_adapter (--detect-middle, scanner_base.py:593-595) upload whole reads.
+ * Instead of one record per read the caller gets what the driver keeps: the histograms of the reads that passed the
+ * minimum-length filter, as counts per (template, barcode of set 0[, barcode of set 1]) and per template.
+ * A record that is not a plain four-line FASTQ / two-line FASTA record: in the first segment QCAT_ERR_UNSUPPORTED before
+ * anything is written (as qcat_fastq_open); later the call ends in front of that record's segment -- a batch boundary --
+ * with stats->incomplete = 1, stats->next_offset = the file offset of the segment's first record and stats->n_reads = the
+ * reads handled so far, and the caller's own parser carries on from there. */
+typedef struct qcat_demux_hist {
+    int32_t w0, w1;            /* in: row widths -- w0 >= the largest set 0, w1 >= the largest set 1 (dual mode), else 1 */
+    int64_t* barcode;          /* out [n_templates * w0 * w1]: kept reads per (template t, barcode b, second barcode b2) at (t * w0 + b) * w1 + b2 */
+    int64_t* adapter;          /* out [n_templates]: kept reads per template of the call */
+    int64_t n_none;            /* out: kept reads without a barcode call */
+    int64_t n_adapter_none;    /* out: kept reads without an adapter */
+} qcat_demux_hist;
+int  qcat_fastq_demux_stream(const char* path, qcat_ctx* ctx, const qcat_kit* kit, const qcat_demux_opts* opts,
+                             qcat_demux_hist* hist, qcat_demux_stats* stats);
+/* the reader stage alone (no device): reads and sequence letters of the file, taken in the same segments (batch_size > 0: cut at
+ * whole batches); *next_offset as stats->next_offset above (the file size when every record is plain). */
+int  qcat_fastq_stream_count(const char* path, uint64_t segment_bytes, uint32_t batch_size, int32_t stream_reader, uint64_t* n_reads,
+                             uint64_t* n_bases, uint64_t* next_offset, uint32_t* n_segments);
 
 /* ---- multi-GPU: reads are sharded by rank, the count vector is the only exchange ----
  * One communicator per (context, rank); RCCL underneath (librccl is opened on the first call here).

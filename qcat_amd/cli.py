@@ -175,11 +175,14 @@ def _fasta_records(handle):
         yield title, "".join(chunks).replace(" ", "").replace("\r", "")
 
 
-def iter_fastx(reads_fx, fastq, batchsize):
-    """Yield (names, comments, seqs, quals) lists of at most ``batchsize`` reads."""
+def iter_fastx(reads_fx, fastq, batchsize, offset=0):
+    """Yield (names, comments, seqs, quals) lists of at most ``batchsize`` reads; ``offset``: the byte of the file to start
+    at (a record start: where the native loop handed the file back, ``_native_demux``)."""
     names, comments, seqs, quals = [], [], [], []
     handle = open(reads_fx) if reads_fx else sys.stdin
     try:
+        if offset:
+            handle.seek(offset)
         records = _fastq_records(handle) if fastq else ((t, s, None) for t, s in _fasta_records(handle))
         try:
             for title, seq, qual in records:
@@ -205,8 +208,9 @@ def iter_fastx(reads_fx, fastq, batchsize):
 class _Outputs(object):
     """Per-barcode files (``-b``) or one annotated stream (``-o`` / stdout)."""
 
-    def __init__(self, out_folder, stream, fastq):
+    def __init__(self, out_folder, stream, fastq, append=False):
         self.folder, self.stream, self.fastq, self.files = out_folder, stream, fastq, {}
+        self.append = append                       # the native loop wrote the first part of the per-barcode files
         if out_folder and not os.path.exists(out_folder):
             os.makedirs(out_folder)
 
@@ -221,7 +225,7 @@ class _Outputs(object):
                     key = key.replace("/", "_")
             fh = self.files.get(key)
             if fh is None:
-                fh = self.files[key] = open(os.path.join(self.folder, key + (".fastq" if self.fastq else ".fasta")), "w")
+                fh = self.files[key] = open(os.path.join(self.folder, key + (".fastq" if self.fastq else ".fasta")), "a" if self.append else "w")
         else:
             fh = self.stream
             comment = "{} barcode={}".format(comment, str(result["barcode"].id) if result["barcode"] else "none")
@@ -281,79 +285,55 @@ class _FdSink(object):
             self.tmp.close()
 
 
-def _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_length, qcat_config, tsv_stream):
-    """The read loop of ``qcat_cli`` inside the native library (``qcat_fastq_open`` / ``qcat_fastq_demux``,
-    include/qcat_hip.h).  Returns (barcode_dist, adapter_dist, total, skipped) or None when the file or the kit is
-    outside what the native path covers (then nothing has been written)."""
-    import numpy as np
+def _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_length, qcat_config, tsv_stream,
+                  filter_barcodes=False):
+    """The read loop of ``qcat_cli`` inside the native library (``qcat_fastq_demux_stream``, include/qcat_hip.h): the file in
+    segments through read | scan | write, whatever its size.  Returns (barcode_dist, adapter_dist, total, skipped,
+    resume offset or None) or None when the file or the kit is outside what the native path covers (then nothing has been
+    written).  A resume offset means the native loop ended in front of a record that is not a plain one (a wrapped or blank
+    line ...): the reads before it are done and written, the caller's own parser takes the rest of the file."""
     from . import native
     layouts = detector.layouts
     if not layouts:
         return None
+    one_kit = len(set(l.kit for l in layouts)) == 1
+    kit_auto = (not nobatch) and not one_kit            # per-batch vote (detect_barcode_batch); one kit: nothing to vote on
+    kit = detector._native_kit(layouts, qcat_config, native.ENDS_BOTH)
+    if out and not os.path.exists(out):
+        os.makedirs(out)
+    tsv_sink = _FdSink(tsv_stream) if tsv else None
+    out_sink = _FdSink(stream) if (not out and not tsv) else None
+    dual = detector._native_mode == "dual"
     try:
-        fq = native.FastqFile(reads_fq)
+        bc, ad, n_none, n_ad_none, stats = native.FastqFile.demux_stream(
+            reads_fq, detector._context(), kit, layouts, dual, batch_size=BATCH_SIZE, kit_auto=kit_auto, trim=trim,
+            min_read_length=min_read_length, tsv_fd=tsv_sink.fd if tsv_sink else None, out_fd=out_sink.fd if out_sink else None,
+            out_dir=out if out else None, filter_barcodes=bool(filter_barcodes) and not nobatch,
+            segment_bytes=int(os.environ.get("QCAT_AMD_SEGMENT_BYTES", "0") or 0))
     except native.FastqFile.Unsupported:
         return None
-    try:
-        one_kit = len(set(l.kit for l in layouts)) == 1
-        kit_auto = (not nobatch) and not one_kit            # per-batch vote (detect_barcode_batch); one kit: nothing to vote on
-        kit = detector._native_kit(layouts, qcat_config, native.ENDS_BOTH)
-        if out and not os.path.exists(out):
-            os.makedirs(out)
-        tsv_sink = _FdSink(tsv_stream) if tsv else None
-        out_sink = _FdSink(stream) if (not out and not tsv) else None
-        try:
-            recs, skipped, _stats = fq.demux(detector._context(), kit, layouts, detector._native_mode == "dual",
-                                             batch_size=BATCH_SIZE, kit_auto=kit_auto, trim=trim, min_read_length=min_read_length,
-                                             tsv_fd=tsv_sink.fd if tsv_sink else None, out_fd=out_sink.fd if out_sink else None,
-                                             out_dir=out if out else None)
-        except native.FastqFile.Unsupported:
-            return None
-        finally:
-            pass
-        for sink in (tsv_sink, out_sink):
-            if sink:
-                sink.finish()
-    finally:
-        fq.close()
-    # the histograms of qcat/cli.py:366-383 from the records (reads the minimum-length filter dropped are not counted):
-    # bincounts over small integer keys -- template index, and (template, barcode[, second barcode]) packed densely
-    keep = skipped == 0
-    a = recs["adapter_idx"][keep].astype(np.int64)
-    b = recs["barcode_idx"][keep].astype(np.int64)
+    for sink in (tsv_sink, out_sink):
+        if sink:
+            sink.finish()
+    # the histograms of qcat/cli.py:366-383 from the native counts (reads the minimum-length filter dropped are not counted)
     adapter_dist, barcode_dist = {}, {}
-    for t, cnt in enumerate(np.bincount(a + 1, minlength=len(layouts) + 1).tolist()):
+    for t, cnt in enumerate(ad.tolist()):
         if cnt:
-            key = layouts[t - 1].kit if t > 0 else "none"
-            adapter_dist[key] = adapter_dist.get(key, 0) + cnt
-    dual = detector._native_mode == "dual"
-    # the same guard as the native writers (fastq_host.inc): a call needs every index inside its table -- a record with a
-    # barcode but no adapter, or a dual record without its second barcode, counts as "none" instead of giving bincount a
-    # negative key
-    called = (b >= 0) & (a >= 0)
-    b2 = recs["barcode2_idx"][keep].astype(np.int64) if dual else None
-    if dual:
-        called &= b2 >= 0
-    n_none = int(len(b) - int(called.sum()))
+            adapter_dist[layouts[t].kit] = adapter_dist.get(layouts[t].kit, 0) + cnt
+    if n_ad_none:
+        adapter_dist["none"] = n_ad_none
     if n_none:
         barcode_dist["none"] = n_none
-    w0 = 1 + max(len(l.get_barcode_set(0) or ()) for l in layouts)
-    w1 = 1 + (max(len(l.get_barcode_set(1) or ()) for l in layouts) if dual else 0)
-    keys = (a[called] * w0 + b[called]) * w1
-    if dual:
-        keys = keys + b2[called]
-    for k, cnt in enumerate(np.bincount(keys, minlength=1).tolist()):
-        if not cnt:
-            continue
-        t, i, j = k // (w0 * w1), (k // w1) % w0, k % w1
+    import numpy as np
+    for t, i, j in zip(*np.nonzero(bc)):
         first = layouts[t].get_barcode_set(0)[i]
         if dual:
             second = layouts[t].get_barcode_set(1)[j]
             name = "barcode{:02d}/{:02d}".format(first.id, second.id)
         else:
             name = first.name
-        barcode_dist[name] = barcode_dist.get(name, 0) + cnt
-    return barcode_dist, adapter_dist, fq.n_reads, int(skipped.sum())
+        barcode_dist[name] = barcode_dist.get(name, 0) + int(bc[t, i, j])
+    return barcode_dist, adapter_dist, stats["n_reads"], stats["n_skipped"], (stats["next_offset"] if stats["incomplete"] else None)
 
 
 def qcat_cli(reads_fq, kit, mode, nobatch, out, min_qual, tsv, output, threads, trim, adapter_yaml, quiet,
@@ -368,13 +348,16 @@ def qcat_cli(reads_fq, kit, mode, nobatch, out, min_qual, tsv, output, threads, 
     fastq = is_fastq(reads_fq)
     stream = open(output, "w") if output else sys.stdout
     native_done = None
-    if reads_fq and not middle_adapter and not filter_barcodes and mode in ("epi2me", "dual") \
-            and not os.environ.get("QCAT_AMD_NO_NATIVE_FASTQ"):
-        # plain four-line FASTQ files and plain two-line FASTA files go through the native ingest / egress (qcat_fastq_demux):
-        # same outputs, no Python string per read; anything else (stdin, wrapped or odd records, rare options) stays on the loop below
-        native_done = _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_length, qcat_config, tsv_stream)
+    if reads_fq and mode in ("epi2me", "dual") and not os.environ.get("QCAT_AMD_NO_NATIVE_FASTQ"):
+        # plain four-line FASTQ files and plain two-line FASTA files go through the native ingest / egress
+        # (qcat_fastq_demux_stream): same outputs, no Python string per read, --detect-middle and --filter-barcodes included;
+        # anything else (stdin, wrapped or odd records, simple mode) stays on -- or comes back to -- the loop below
+        native_done = _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_length, qcat_config, tsv_stream,
+                                    filter_barcodes=filter_barcodes)
+    barcode_dist, adapter_dist, total_reads, skipped_reads, resume = {}, {}, 0, 0, 0
     if native_done is not None:
-        barcode_dist, adapter_dist, total_reads, skipped_reads = native_done
+        barcode_dist, adapter_dist, total_reads, skipped_reads, resume = native_done
+    if native_done is not None and resume is None:
         if not quiet:
             for line in histogram_lines(barcode_dist, adapter_dist, total_reads):
                 logging.info(line)
@@ -383,9 +366,8 @@ def qcat_cli(reads_fq, kit, mode, nobatch, out, min_qual, tsv, output, threads, 
         if output:
             stream.close()
         return barcode_dist, adapter_dist, total_reads, skipped_reads
-    outputs = _Outputs(out, stream, fastq)
-    barcode_dist, adapter_dist, total_reads, skipped_reads = {}, {}, 0, 0
-    for names, comments, seqs, quals in iter_fastx(reads_fq, fastq, 1 if nobatch else BATCH_SIZE):
+    outputs = _Outputs(out, stream, fastq, append=bool(resume))
+    for names, comments, seqs, quals in iter_fastx(reads_fq, fastq, 1 if nobatch else BATCH_SIZE, offset=resume or 0):
         if nobatch:
             results = [detector.detect_barcode(read_sequence=seqs[0], read_qualities=quals[0], qcat_config=qcat_config)]
         else:

@@ -1810,6 +1810,7 @@ extern "C" int qcat_sg_align(qcat_ctx* c, const uint8_t* queries, const uint64_t
 // native FASTQ ingest and egress
 // ------------------------------------------------------------------------------------------
 #include "fastq_host.inc"
+#include "fastq_stream.inc"
 
 // ------------------------------------------------------------------------------------------
 // multi-GPU count reduction (RCCL)

@@ -12,7 +12,7 @@ import threading
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MODE_EPI2ME, MODE_DUAL, MODE_SIMPLE = 0, 1, 2
 ENDS_5P, ENDS_BOTH = 1, 3
 MAX_TEMPLATES = 16
@@ -80,12 +80,20 @@ class DemuxOpts(C.Structure):
     _fields_ = [("batch_size", C.c_int32), ("kit_auto", C.c_int32), ("trim", C.c_int32), ("min_read_length", C.c_int32),
                 ("tsv", C.c_int32), ("tsv_fd", C.c_int32), ("out_fd", C.c_int32), ("out_dir", C.c_char_p),
                 ("kit_name", C.POINTER(C.c_char_p)), ("bc_name", C.POINTER(C.POINTER(C.c_char_p))),
-                ("bc_id", C.POINTER(C.POINTER(C.c_int32))), ("bc2_id", C.POINTER(C.POINTER(C.c_int32)))]
+                ("bc_id", C.POINTER(C.POINTER(C.c_int32))), ("bc2_id", C.POINTER(C.POINTER(C.c_int32))),
+                ("filter_barcodes", C.c_int32), ("stream_reader", C.c_int32), ("segment_bytes", C.c_uint64)]
 
 
 class DemuxStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_skipped", C.c_uint64), ("file_bytes", C.c_uint64),
-                ("parse_s", C.c_double), ("scan_s", C.c_double), ("write_s", C.c_double), ("total_s", C.c_double)]
+                ("parse_s", C.c_double), ("scan_s", C.c_double), ("write_s", C.c_double), ("total_s", C.c_double),
+                ("next_offset", C.c_uint64), ("incomplete", C.c_int32), ("segments", C.c_int32)]
+
+
+class DemuxHist(C.Structure):
+    """qcat_demux_hist (include/qcat_hip.h)"""
+    _fields_ = [("w0", C.c_int32), ("w1", C.c_int32), ("barcode", C.POINTER(C.c_int64)), ("adapter", C.POINTER(C.c_int64)),
+                ("n_none", C.c_int64), ("n_adapter_none", C.c_int64)]
 
 
 class KitDescriptor(object):
@@ -322,6 +330,9 @@ class HipLibrary(object):
             "qcat_fastq_close": (None, [vp]),
             "qcat_fastq_read_info": (C.c_int, [vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(u32), C.POINTER(C.c_uint64), C.POINTER(u32)]),
             "qcat_fastq_demux": (C.c_int, [vp, vp, vp, C.POINTER(DemuxOpts), vp, vp, C.POINTER(DemuxStats)]),
+            "qcat_fastq_demux_stream": (C.c_int, [C.c_char_p, vp, vp, C.POINTER(DemuxOpts), C.POINTER(DemuxHist), C.POINTER(DemuxStats)]),
+            "qcat_fastq_stream_count": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
             "qcat_comm_unique_id": (C.c_int, [vp]),
             "qcat_comm_create": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
             "qcat_comm_destroy": (None, [vp]),
@@ -624,10 +635,9 @@ class FastqFile(object):
         self.hip.check(self.hip.lib.qcat_fastq_read_info(self.handle, r, C.byref(to), C.byref(tl), C.byref(so), C.byref(sl)))
         return int(to.value), int(tl.value), int(so.value), int(sl.value)
 
-    def demux(self, ctx, kit, layouts, dual, batch_size=4000, kit_auto=False, trim=False, min_read_length=0,
-              tsv_fd=None, out_fd=None, out_dir=None):
-        """qcat_fastq_demux: scan + write; returns (records, skipped flags, stats dict).  ``layouts``: the AdapterLayout
-        list of ``kit`` (the names the writers print)."""
+    @staticmethod
+    def _demux_opts(layouts, dual, batch_size, kit_auto, trim, min_read_length, tsv_fd, out_fd, out_dir, filter_barcodes, segment_bytes, reader=0):
+        """a qcat_demux_opts and the buffers it points to"""
         n_t = len(layouts)
         keep = []
         kit_names = (C.c_char_p * n_t)(*[str(l.kit).encode() for l in layouts])
@@ -644,12 +654,21 @@ class FastqFile(object):
             bc_name[t] = C.cast(names, C.POINTER(C.c_char_p))
             bc_id[t] = C.cast(ids, C.POINTER(C.c_int32))
             bc2_id[t] = C.cast(ids2, C.POINTER(C.c_int32))
+        keep += [kit_names, bc_name, bc_id, bc2_id]
         o = DemuxOpts(batch_size=batch_size, kit_auto=1 if kit_auto else 0, trim=1 if trim else 0,
                       min_read_length=int(min_read_length), tsv=1 if tsv_fd is not None else 0,
                       tsv_fd=-1 if tsv_fd is None else tsv_fd, out_fd=-1 if out_fd is None else out_fd,
                       out_dir=os.fsencode(out_dir) if out_dir else None,
                       kit_name=C.cast(kit_names, C.POINTER(C.c_char_p)), bc_name=C.cast(bc_name, C.POINTER(C.POINTER(C.c_char_p))),
-                      bc_id=C.cast(bc_id, C.POINTER(C.POINTER(C.c_int32))), bc2_id=C.cast(bc2_id, C.POINTER(C.POINTER(C.c_int32))))
+                      bc_id=C.cast(bc_id, C.POINTER(C.POINTER(C.c_int32))), bc2_id=C.cast(bc2_id, C.POINTER(C.POINTER(C.c_int32))),
+                      filter_barcodes=1 if filter_barcodes else 0, stream_reader=int(reader), segment_bytes=int(segment_bytes or 0))
+        return o, keep
+
+    def demux(self, ctx, kit, layouts, dual, batch_size=4000, kit_auto=False, trim=False, min_read_length=0,
+              tsv_fd=None, out_fd=None, out_dir=None, filter_barcodes=False):
+        """qcat_fastq_demux: scan + write; returns (records, skipped flags, stats dict).  ``layouts``: the AdapterLayout
+        list of ``kit`` (the names the writers print)."""
+        o, _keep = self._demux_opts(layouts, dual, batch_size, kit_auto, trim, min_read_length, tsv_fd, out_fd, out_dir, filter_barcodes, 0)
         recs = np.zeros(self.n_reads, dtype=RESULT_DTYPE)
         skipped = np.zeros(self.n_reads, dtype=np.uint8)
         st = DemuxStats()
@@ -659,6 +678,45 @@ class FastqFile(object):
         self.hip.check(rc)
         return recs, skipped, {"n_reads": int(st.n_reads), "n_skipped": int(st.n_skipped), "file_bytes": int(st.file_bytes),
                                "parse_s": st.parse_s, "scan_s": st.scan_s, "write_s": st.write_s, "total_s": st.total_s}
+
+    @staticmethod
+    def stream_count(path, segment_bytes=0, batch_size=0, reader=0):
+        """qcat_fastq_stream_count: (reads, sequence letters, next offset, segments) of a file through the reader stage of
+        qcat_fastq_demux_stream (no device needed)."""
+        hip = HipLibrary.get()
+        n, nb, off, segs = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        rc = hip.lib.qcat_fastq_stream_count(os.fsencode(path), int(segment_bytes), int(batch_size), int(reader), C.byref(n), C.byref(nb), C.byref(off), C.byref(segs))
+        if rc == -2:
+            raise FastqFile.Unsupported((hip.lib.qcat_last_error() or b"").decode("utf-8", "replace"))
+        hip.check(rc)
+        return int(n.value), int(nb.value), int(off.value), int(segs.value)
+
+    @staticmethod
+    def demux_stream(path, ctx, kit, layouts, dual, batch_size=4000, kit_auto=False, trim=False, min_read_length=0,
+                     tsv_fd=None, out_fd=None, out_dir=None, filter_barcodes=False, segment_bytes=0, reader=0):
+        """qcat_fastq_demux_stream: the file in segments through read | scan | write, host memory independent of its size.
+        Returns (barcode counts [template][barcode][second barcode], adapter counts [template], reads without a barcode,
+        reads without an adapter, stats dict); ``stats["incomplete"]``: the loop ended at ``stats["next_offset"]`` in front of
+        a record that is not plain -- the caller's own parser carries on from there.  Raises ``Unsupported`` when that is the
+        case for the very first segment (nothing has been written)."""
+        hip = HipLibrary.get()
+        o, _keep = FastqFile._demux_opts(layouts, dual, batch_size, kit_auto, trim, min_read_length, tsv_fd, out_fd, out_dir,
+                                         filter_barcodes, segment_bytes, reader)
+        n_t = len(layouts)
+        w0 = max(1, max(len(l.get_barcode_set(0) or ()) for l in layouts))
+        w1 = max(1, max(len(l.get_barcode_set(1) or ()) for l in layouts)) if dual else 1
+        barcode = np.zeros((n_t, w0, w1), dtype=np.int64)
+        adapter = np.zeros(n_t, dtype=np.int64)
+        h = DemuxHist(w0=w0, w1=w1, barcode=barcode.ctypes.data_as(C.POINTER(C.c_int64)), adapter=adapter.ctypes.data_as(C.POINTER(C.c_int64)))
+        st = DemuxStats()
+        rc = hip.lib.qcat_fastq_demux_stream(os.fsencode(path), ctx.handle, kit.handle, C.byref(o), C.byref(h), C.byref(st))
+        if rc == -2:
+            raise FastqFile.Unsupported((hip.lib.qcat_last_error() or b"").decode("utf-8", "replace"))
+        hip.check(rc)
+        return barcode, adapter, int(h.n_none), int(h.n_adapter_none), {
+            "n_reads": int(st.n_reads), "n_skipped": int(st.n_skipped), "file_bytes": int(st.file_bytes), "parse_s": st.parse_s,
+            "scan_s": st.scan_s, "write_s": st.write_s, "total_s": st.total_s, "next_offset": int(st.next_offset),
+            "incomplete": int(st.incomplete), "segments": int(st.segments)}
 
     def close(self):
         if self.handle:

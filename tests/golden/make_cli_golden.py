@@ -76,6 +76,19 @@ def main():
     jobs.append((cfg1, "config1_lwb001_193.fastq",
                  {"tag": "dir-auto-readme", "kit": "auto", "mode": "epi2me", "nobatch": False, "tsv": False, "trim": False, "min_len": 100, "dir": True}))
     file_kits_all["config1_lwb001_193.fastq"] = synth.CONFIG1["kit"]
+    # round 5: the driver's --detect-middle / --filter-barcodes (qcat/cli.py:165-171 -> scanner_base.py:593-595, :690-712) on a
+    # generated file on which they change the outcome (tests/synth.py: flags_fastq; not committed)
+    flags_lays = [l for l in ref_adapters.populate_adapter_layouts() if l.kit == synth.FLAGS["kit"]]
+    flags_fq = os.path.join(tmpd, "flags_nbd104_150.fastq")
+    with open(flags_fq, "w") as fh:
+        fh.write(synth.flags_fastq(flags_lays))
+    file_kits_all["flags_nbd104_150.fastq"] = synth.FLAGS["kit"]
+    flag_variants = [
+        {"tag": "tsv-kit-middle", "kit": None, "mode": "epi2me", "nobatch": False, "tsv": True, "trim": False, "min_len": 100, "dir": False, "middle": True, "filter": False},
+        {"tag": "tsv-auto-filter-trim", "kit": "auto", "mode": "epi2me", "nobatch": False, "tsv": True, "trim": True, "min_len": 100, "dir": False, "middle": False, "filter": True},
+        {"tag": "dir-auto-middle-filter-trim", "kit": "auto", "mode": "epi2me", "nobatch": False, "tsv": False, "trim": True, "min_len": 0, "dir": True, "middle": True, "filter": True},
+        {"tag": "tsv-auto-nobatch-middle-filter", "kit": "auto", "mode": "epi2me", "nobatch": True, "tsv": True, "trim": False, "min_len": 100, "dir": False, "middle": True, "filter": True},
+    ]
     # FASTA input (qcat/cli.py:235-306 reads it with SimpleFastaParser, the writers then produce FASTA): the plain two-line
     # FASTA of a shipped FASTQ file, derived here and in the test by fasta_of_fastq (not committed)
     only_fasta = "--only-fasta" in sys.argv
@@ -86,9 +99,17 @@ def main():
         jobs = []
     jobs += [(fa, "fasta_of_nbd103.fasta", v) for v in variants if v["tag"] in ("tsv-auto-batch", "dir-auto-trim", "stream-kit-trim-minlen1000")]
     file_kits_all["fasta_of_nbd103.fasta"] = file_kits["nbd103.fastq"]
+    only_flags = "--only-flags" in sys.argv
+    if only_flags:
+        jobs = []
+    if not only_config1 and not only_fasta:
+        jobs += [(flags_fq, "flags_nbd104_150.fastq", v) for v in flag_variants]
     if only_fasta:
         with open(os.path.join(HERE, "cli_golden.json")) as fh:
             runs = [r for r in json.load(fh)["runs"] if not r["file"].startswith("fasta_of_")]
+    if only_flags:
+        with open(os.path.join(HERE, "cli_golden.json")) as fh:
+            runs = [r for r in json.load(fh)["runs"] if not r["file"].startswith("flags_")]
     if only_config1:
         with open(os.path.join(HERE, "cli_golden.json")) as fh:
             runs = [r for r in json.load(fh)["runs"] if not r["file"].startswith("config1_")]
@@ -103,8 +124,8 @@ def main():
             with contextlib.redirect_stdout(buf):
                 ref_cli.qcat_cli(reads_fq=path, kit=kit, mode=v["mode"], nobatch=v["nobatch"],
                                  out=outdir, min_qual=None, tsv=v["tsv"], output=None if v["dir"] else outfile,
-                                 threads=1, trim=v["trim"], adapter_yaml=None, quiet=False, filter_barcodes=False,
-                                 middle_adapter=False, min_read_length=v["min_len"], qcat_config=cfg)
+                                 threads=1, trim=v["trim"], adapter_yaml=None, quiet=False, filter_barcodes=v.get("filter", False),
+                                 middle_adapter=v.get("middle", False), min_read_length=v["min_len"], qcat_config=cfg)
             files = {}
             if outdir:
                 for f in sorted(os.listdir(outdir)):

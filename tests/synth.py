@@ -128,3 +128,24 @@ def config1_fastq(layouts):
                          force_barcode=0, force_bare=(i in c["bare_at"]))
         lines += ["@read%03d runid=config1 ch=%d" % (i, 1 + i % 512), seq, "+", "I" * len(seq)]
     return "\n".join(lines) + "\n"
+
+
+FLAGS = {"seed": 20260930, "n": 150, "error_rate": 0.06, "insert_len": 120, "kit": "NBD104/NBD114"}
+
+
+def flags_fastq(layouts):
+    """A small file on which the driver's rarely used flags DO something (round 5: --detect-middle and --filter-barcodes on
+    the native file path; golden runs of the reference driver with the flags set, tests/golden/make_cli_golden.py): 150 reads of
+    kit NBD104/NBD114 -- 60 % barcode 1, 30 % barcode 2, every tenth read one of a dozen barcodes seen once or twice (the
+    per-batch filter of qcat/scanner_base.py:690-712 drops those), every sixth read a chimera of a read with itself or with its
+    reverse complement (an adapter with the same barcode in the interior: exit status 997 under --detect-middle,
+    scanner_base.py:479-519, :593-595).  ``layouts`` = the kit's templates in sorted order.  Returns the file's text."""
+    c = FLAGS
+    lines = []
+    for i in range(c["n"]):
+        b = (2 + i // 10) if i % 10 == 9 else (0 if i % 10 < 6 else 1)
+        seq = synth_read(i, c["seed"], layouts, 1, 0, error_rate=c["error_rate"], insert_len=c["insert_len"], force_barcode=b)
+        if i % 6 == 2:
+            seq = seq + (revcomp_acgt(seq) if i % 12 == 2 else seq)
+        lines += ["@read%03d runid=flags ch=%d" % (i, 1 + i % 512), seq, "+", "I" * len(seq)]
+    return "\n".join(lines) + "\n"

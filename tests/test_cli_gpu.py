@@ -53,6 +53,13 @@ def test_cli_matches_reference_driver(idx, tmp_path):
         reads_fq = str(tmp_path / run["file"])
         with open(reads_fq, "w") as fh:
             fh.write(synth.config1_fastq(scanner.factory(kit=synth.CONFIG1["kit"]).layouts))
+    if run["file"].startswith("flags_"):
+        # round 5: the file on which --detect-middle / --filter-barcodes change the outcome, regenerated from its seed
+        import synth
+        from qcat_amd import scanner
+        reads_fq = str(tmp_path / run["file"])
+        with open(reads_fq, "w") as fh:
+            fh.write(synth.flags_fastq(scanner.factory(kit=synth.FLAGS["kit"]).layouts))
     if run["file"].startswith("fasta_of_"):
         # FASTA input: the plain two-line FASTA of a shipped FASTQ file, derived as tests/golden/make_cli_golden.py derives it
         src = os.path.join(helpers.GOLDEN, "data", run["file"][len("fasta_of_"):].replace(".fasta", ".fastq"))
@@ -65,7 +72,7 @@ def test_cli_matches_reference_driver(idx, tmp_path):
         cli.qcat_cli(reads_fq=reads_fq, kit=run["kit"], mode=v["mode"],
                      nobatch=v["nobatch"], out=outdir, min_qual=None, tsv=v["tsv"],
                      output=None if v["dir"] else outfile, threads=1, trim=v["trim"], adapter_yaml=None,
-                     quiet=False, filter_barcodes=False, middle_adapter=False, min_read_length=v["min_len"],
+                     quiet=False, filter_barcodes=v.get("filter", False), middle_adapter=v.get("middle", False), min_read_length=v["min_len"],
                      qcat_config=config.get_default_config(), tsv_stream=buf)
     finally:
         root.removeHandler(cap)

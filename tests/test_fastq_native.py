@@ -106,3 +106,73 @@ def test_empty_file_and_missing_file(tmp_path):
     fq.close()
     with pytest.raises(RuntimeError):
         native.FastqFile(str(tmp_path / "nope.fastq"))
+
+
+# ---- the reader stage of qcat_fastq_demux_stream (csrc/fastq_stream.inc): segments, carries, batch cuts -----------------------
+
+def _awkward_fastq(path, n, seed, newline_at_end=True):
+    rng = random.Random(seed)
+    lines, bases = [], 0
+    for i in range(n):
+        k = rng.randrange(1, 400)
+        seq = "".join(rng.choice("ACGTN") for _ in range(k))
+        qual = "".join(rng.choice("@+!I5#") for _ in range(k))
+        title = "read%d" % i + rng.choice(["", " ch=1", "\tcomment with\ttabs", " trailing  "])
+        lines += ["@" + title, seq, "+" + (title.rstrip() if i % 7 == 0 else ""), qual]
+        bases += k
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + ("\n" if newline_at_end else ""))
+    return bases
+
+
+@pytest.mark.parametrize("segment_bytes,batch", [(64, 0), (1000, 0), (1000, 7), (4096, 100), (100000, 4000), (1 << 20, 0), (0, 4000)])
+def test_streamed_segments_see_every_read_once(segment_bytes, batch, tmp_path, monkeypatch):
+    """Segments far smaller than a record, than a batch, or bigger than the file; quality lines that start with '@' / '+';
+    with and without a final newline: the reads and letters of all rounds add up to the file's, whatever the cut."""
+    monkeypatch.setenv("QCAT_HOST_THREADS", "3")
+    for nl in (True, False):
+        path = str(tmp_path / ("awk%d.fastq" % nl))
+        bases = _awkward_fastq(path, 3000, 5, newline_at_end=nl)
+        n, nb, off, segs = native.FastqFile.stream_count(path, segment_bytes, batch)
+        assert (n, nb, off) == (3000, bases, os.path.getsize(path))
+        assert native.FastqFile.stream_count(path, segment_bytes, batch, reader=2) == (n, nb, off, segs)     # mapped windows instead of pread
+        # (a batch that holds the whole file makes ONE round of it, however small the segments)
+        assert segs >= 1 and (segment_bytes == 0 or segment_bytes >= (1 << 20) or batch >= 3000 or segs > 1)
+
+
+def test_streamed_segments_of_a_big_file_split_on_several_threads(tmp_path, monkeypatch):
+    monkeypatch.setenv("QCAT_HOST_THREADS", "5")
+    path = str(tmp_path / "big.fastq")
+    bases = _awkward_fastq(path, 120000, 9)
+    assert os.path.getsize(path) > 40 << 20
+    for seg, batch in ((16 << 20, 4000), (7 << 20, 0)):
+        for reader in (1, 2):
+            n, nb, off, segs = native.FastqFile.stream_count(path, seg, batch, reader=reader)
+            assert (n, nb, off) == (120000, bases, os.path.getsize(path)) and segs >= 3
+
+
+def test_streamed_fasta_and_the_hand_back_at_a_record_that_is_not_plain(tmp_path):
+    rng = random.Random(3)
+    recs = [(">r%d c=%d" % (i, i), "".join(rng.choice("ACGT") for _ in range(rng.randrange(1, 300)))) for i in range(2000)]
+    path = str(tmp_path / "plain.fasta")
+    with open(path, "w") as fh:
+        fh.write("".join(t + "\n" + s + "\n" for t, s in recs))
+    n, nb, off, _ = native.FastqFile.stream_count(path, 5000, 50)
+    assert (n, nb, off) == (2000, sum(len(s) for _t, s in recs), os.path.getsize(path))
+    # a wrapped record in the middle: the rounds end in front of ITS segment, at a batch boundary, and say where
+    text = "".join("@q%d\n%s\n+\n%s\n" % (i, "ACGT" * 20, "I" * 80) for i in range(1000))
+    bad = text + "@wrapped\nACGT\nACGT\n+\nIIIIIIII\n" + "".join("@z%d\nAC\n+\nII\n" % i for i in range(10))
+    path = str(tmp_path / "wrapped_later.fastq")
+    with open(path, "w") as fh:
+        fh.write(bad)
+    n, _nb, off, _ = native.FastqFile.stream_count(path, 10000, 10)
+    assert 0 < n < 1000 and n % 10 == 0 and bad[off:off + 2] == "@q" and bad[:off].count("\n") == 4 * n
+    # ... and in the very first segment nothing is handed out at all
+    path = str(tmp_path / "wrapped_first.fastq")
+    with open(path, "w") as fh:
+        fh.write("@wrapped\nACGT\nACGT\n+\nIIIIIIII\n" + text)
+    with pytest.raises(native.FastqFile.Unsupported):
+        native.FastqFile.stream_count(path, 10000, 10)
+    empty = str(tmp_path / "empty.fastq")
+    open(empty, "w").close()
+    assert native.FastqFile.stream_count(empty)[:2] == (0, 0)

@@ -107,3 +107,16 @@ def test_simple_barcodes_of_unequal_length_match_the_reference_and_the_oracle(i,
     got = native.NativeContext(0).scan(native.NativeKit(d), *native.pack_reads(many), counts=cnt)
     want, want_cnt = oracle_lib.scan(d, many, counts=True, threads=8)
     assert got.tobytes() == want.tobytes() and np.array_equal(cnt, want_cnt)
+    # scan() of sequences LONGER than max_align_length takes qcat_scan_sequences (k_scan_sequences): every barcode with its own
+    # length there too, winners compared by normalised score (that branch aligned over the padded row)
+    longs = [r + "ACGGTTCA" * 40 for r in reads[:12] if len(r) > 30] + [reads[0][:151], "GATTACA" * 100]
+    assert all(len(q) > cfg.max_align_length for q in longs)
+    d5 = det.descriptor(ends=native.ENDS_5P)
+    got = native.NativeContext(0).scan_sequences(native.NativeKit(d5), *native.pack_reads(longs))
+    assert got.tobytes() == oracle_lib.scan_sequences(d5, longs).tobytes()
+    assert (got["barcode_idx"] >= 0).sum() >= 3
+    for q, rec in zip(longs[:4], got[:4]):
+        one = det.scan(q, None, [], [], qcat_config=cfg)
+        assert one["adapter_end"] == int(rec["adapter_end"])
+        assert (det.barcodes.index(one["barcode"]) if one["barcode"] else -1) == int(rec["barcode_idx"])
+

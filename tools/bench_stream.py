@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""The host side of the file loop on the GPU box: the reader stage alone (qcat_fastq_stream_count: pread / mapped windows,
+segment sizes), the whole-file index (qcat_fastq_open), and the streamed demux against the whole-file demux, TSV to a file.
+    python tools/bench_stream.py [reads] [out.json]"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np                     # noqa: E402
+import synth                           # noqa: E402
+from qcat_amd import config, native, scanner   # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+det = scanner.factory(kit="PBC096")
+block = synth.synth_batch(20000, 3, det.layouts, 1, 0, error_rate=0.08)
+tmp = tempfile.mkdtemp(prefix="qcat_bs_")
+path = os.path.join(tmp, "reads.fastq")
+with open(path, "wb") as fh:
+    i = 0
+    while i < n:
+        part = block[:min(len(block), n - i)]
+        fh.write("".join("@r%d ch=%d\n%s\n+\n%s\n" % (i + k, k % 512, r, "I" * len(r)) for k, r in enumerate(part)).encode())
+        i += len(part)
+size = os.path.getsize(path)
+res = {"reads": n, "file_gb": round(size / 1e9, 3), "reader": [], "demux": []}
+
+
+def best_of(f, k=3):
+    b = None
+    for _ in range(k):
+        t = time.perf_counter()
+        r = f()
+        dt = time.perf_counter() - t
+        if b is None or dt < b[0]:
+            b = (dt, r)
+    return b
+
+
+dt, _ = best_of(lambda: native.FastqFile(path).close())
+res["open_index_ms"] = round(dt * 1e3, 2)
+for reader in (1, 2):
+    for seg in (32 << 20, 64 << 20, 128 << 20, 256 << 20):
+        dt, r = best_of(lambda: native.FastqFile.stream_count(path, seg, 4000, reader))
+        assert r[0] == n
+        res["reader"].append({"reader": reader, "segment_mb": seg >> 20, "ms": round(dt * 1e3, 2), "gb_per_s": round(size / dt / 1e9, 1)})
+cfg = config.qcatConfig()
+kit = det._native_kit(det.layouts, cfg, native.ENDS_BOTH)
+ctx = det._context()
+with open(os.path.join(tmp, "a.tsv"), "wb") as sink:
+    def whole():
+        sink.seek(0)
+        f = native.FastqFile(path)
+        out = f.demux(ctx, kit, det.layouts, False, trim=True, tsv_fd=sink.fileno())[2]
+        f.close()
+        return out
+    dt, st = best_of(whole)
+    res["whole_file"] = {"ms": round(dt * 1e3, 2), "m_reads_per_s": round(n / dt / 1e6, 2), "split_s": {k: round(v, 4) for k, v in st.items() if k.endswith("_s")}}
+    for reader in (1, 2):
+        for seg in (64 << 20, 128 << 20, 256 << 20):
+            def stream():
+                sink.seek(0)
+                return native.FastqFile.demux_stream(path, ctx, kit, det.layouts, False, trim=True, tsv_fd=sink.fileno(), segment_bytes=seg, reader=reader)[4]
+            dt, st = best_of(stream)
+            res["demux"].append({"reader": reader, "segment_mb": seg >> 20, "ms": round(dt * 1e3, 2), "m_reads_per_s": round(n / dt / 1e6, 2),
+                                 "split_s": {k: round(v, 4) for k, v in st.items() if k.endswith("_s")}})
+os.remove(path)
+for f in os.listdir(tmp):
+    os.remove(os.path.join(tmp, f))
+os.rmdir(tmp)
+text = json.dumps(res, indent=1)
+print(text)
+if len(sys.argv) > 2:
+    with open(sys.argv[2], "w") as fh:
+        fh.write(text + "\n")
