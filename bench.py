@@ -58,6 +58,9 @@ WORKLOADS = {
     # the reference driver's call shape (qcat/cli.py:500-513): kit auto (12 templates), detect_barcode_batch on batches
     # of 4000 reads, results as Python dicts; reads carry PBC096 adapters; host-driven, see api4000()
     "api4000": ("epi2me", None, native.ENDS_BOTH, 3, 2, 324, 200000),
+    # the reference's library / test entry: detect_barcode on ONE read per call (qcat/test/test_barcode.py:84, :309-322;
+    # cli.py:504-509 --no-batch), a named kit and kit auto (all twelve templates, no vote); host-driven, see api1()
+    "api1": ("epi2me", None, native.ENDS_BOTH, 3, 2, 324, 2000),
 }
 HBM_PEAK_GBS = 8000.0
 
@@ -112,7 +115,7 @@ def parse():
     if a.reads is None:
         a.reads = WORKLOADS[a.workload][6]
     if a.seed is None:
-        a.seed = 20260928 + {"config2": 1, "config3": 2, "config4": 3, "dual": 4, "dual96": 4, "middle": 1, "api4000": 2}[a.workload]
+        a.seed = 20260928 + {"config2": 1, "config3": 2, "config4": 3, "dual": 4, "dual96": 4, "middle": 1, "api4000": 2, "api1": 2}[a.workload]
     return a
 
 
@@ -142,6 +145,10 @@ def main():
         sys.exit("bench.py: rank %d needs HIP device %d but only %d device(s) are visible" % (rank, local_rank, n_dev))
 
     mode, kit_name, ends, t5, t3, bytes_per_read, _ = WORKLOADS[a.workload]
+    if a.workload == "api1":
+        if world != 1:
+            sys.exit("bench.py: --workload api1 is a single-process measurement")
+        return api1(a, hip, lib)
     if a.workload == "api4000":
         if world != 1:
             sys.exit("bench.py: --workload api4000 is a single-process measurement")
@@ -607,6 +614,69 @@ def api4000(a, hip, lib):
            "roofline": None, "cpu_baseline": None,
            "note": "host-driven call shape: the GPU kernels of a 4000-read batch take a fraction of the call; "
                    "roofline / cpu_baseline belong to the resident workloads (default run)"}
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
+def api1(a, hip, lib):
+    """The reference's library entry (qcat/test/test_barcode.py:84, :309-322; the driver's --no-batch loop, cli.py:504-509):
+    detect_barcode on ONE read per call, with a named kit (PBC096: two templates) and under kit auto (all twelve auto-detect
+    templates, no vote).  Reads: synthetic PBC096 reads as Python strings.  The split says where a call's time goes."""
+    cfg = qconfig.qcatConfig()
+    gen = scanner.factory(mode="epi2me", kit="PBC096")
+    gkit = native.NativeKit(gen.descriptor(qcat_config=cfg, ends=native.ENDS_BOTH))
+    sp = native.SynthParams(seed=a.seed, n_reads=a.reads, insert_len=600, lead_min=5, lead_max=40,
+                            error_rate=a.error_rate, no_adapter_fraction=0.05, tpl_5p=1, tpl_3p=0)
+    buf = np.zeros(4096, dtype=np.uint8)
+    reads = []
+    for i in range(a.reads):
+        ln = lib.qcat_synth_read(gkit.handle, C.byref(sp), i, buf.ctypes.data, buf.size)
+        reads.append(buf[:ln].tobytes().decode("ascii"))
+    legs = {}
+    for name, det in (("named_kit", gen), ("kit_auto", scanner.factory(mode="epi2me", kit=None))):
+        for r in reads[:max(8, a.warmup)]:
+            det.detect_barcode(r, None, cfg)
+        split = {"pack_reads_s": 0.0, "native_call_s": 0.0, "dicts_s": 0.0}
+        ctx = det._context()
+        orig_scan, orig_pack, orig_dicts = ctx.scan, native.pack_reads, det._records_to_dicts
+
+        def timed(key, fn):
+            def wrap(*args, **kw):
+                t = time.perf_counter()
+                try:
+                    return fn(*args, **kw)
+                finally:
+                    split[key] += time.perf_counter() - t
+            return wrap
+        ctx.scan = timed("native_call_s", orig_scan)
+        native.pack_reads = timed("pack_reads_s", orig_pack)
+        det._records_to_dicts = timed("dicts_s", orig_dicts)
+        t0 = time.perf_counter()
+        called = 0
+        for _ in range(a.steps):
+            for r in reads:
+                called += det.detect_barcode(r, None, cfg)["barcode"] is not None
+        elapsed = time.perf_counter() - t0
+        ctx.scan, native.pack_reads, det._records_to_dicts = orig_scan, orig_pack, orig_dicts
+        n_calls = a.steps * len(reads)
+        # the same reads through one batch call: the single-read calls must give the same results
+        batch = det._run(reads, det.layouts, cfg)
+        single = [det.detect_barcode(r, None, cfg) for r in reads[:200]]
+        if any(s != b for s, b in zip(single, batch[:200])):
+            sys.exit("bench.py: detect_barcode on single reads and on the batch disagree")
+        legs[name] = {"ms_per_call": round(elapsed / n_calls * 1e3, 4), "calls_per_s": round(n_calls / elapsed, 1), "templates": len(det.layouts),
+                      "split_ms_per_call": {k[:-2] + "_ms": round(v / n_calls * 1e3, 4) for k, v in split.items()},
+                      "other_python_ms_per_call": round((elapsed - sum(split.values())) / n_calls * 1e3, 4),
+                      "called_fraction": round(called / float(n_calls), 4)}
+    out = {"metric": "reads/sec demultiplexed", "value": legs["named_kit"]["calls_per_s"], "unit": "reads/s", "n_gpus": 1,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": legs["named_kit"]["ms_per_call"], "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "int16 / bit planes", "data": "synthetic",
+           "config": {"workload": "api1: detect_barcode on ONE read per call (qcat/test/test_barcode.py:84, cli.py:504-509), results as "
+                                  "Python dicts; %d synthetic PBC096 reads as Python strings; value = the named-kit leg; a step here is "
+                                  "one call" % len(reads), "calls": a.steps * len(reads)},
+           "legs": legs, "roofline": None, "cpu_baseline": None,
+           "note": "host-driven call shape: one read is two windows -- the kernels are latency, not throughput; roofline / cpu_baseline "
+                   "belong to the resident workloads (default run)"}
     print(json.dumps(out))
     sys.stdout.flush()
 

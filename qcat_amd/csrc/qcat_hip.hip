@@ -457,7 +457,7 @@ struct qcat_ctx {
         uint64_t prev_kit = 0, prev_bases = 0, prev_gen = 0; uint32_t prev_reads = 0, prev_batch = 0;   // the shape of the last call
         int failures = 0;                                                         // captures that did not work out (two: never again)
         uint64_t replays = 0;
-    } api_graph;
+    } api_graph, scan_graph;                       // kit-auto calls (scan_batch_auto_impl); calls with a named kit (qcat_scan_batch, round 5)
     // debug buffers
     int32_t* dbg_tpl = nullptr; size_t cap_dbg_tpl = 0;
     int16_t* dbg_rows = nullptr; size_t cap_dbg_rows = 0;
@@ -498,6 +498,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->api_graph.exec) (void)hipGraphExecDestroy(c->api_graph.exec);
+    if (c->scan_graph.exec) (void)hipGraphExecDestroy(c->scan_graph.exec);
     (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->wspec); (void)hipFree(c->win2); (void)hipFree(c->recs); (void)hipFree(c->results);
     (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows);
     (void)hipFree(c->hb_bases); (void)hipFree(c->hb_offsets); (void)hipFree(c->hb_len); (void)hipFree(c->vote_buf);
@@ -957,7 +958,7 @@ extern "C" int qcat_ctx_fetch_counts(qcat_ctx* c, int64_t* counts, int32_t n_buc
 }
 
 extern "C" void* qcat_ctx_stream(qcat_ctx* c) { return c ? (void*)c->stream : nullptr; }
-extern "C" int64_t qcat_ctx_graph_replays(const qcat_ctx* c) { return c ? (int64_t)c->api_graph.replays : -1; }
+extern "C" int64_t qcat_ctx_graph_replays(const qcat_ctx* c) { return c ? (int64_t)(c->api_graph.replays + c->scan_graph.replays) : -1; }
 // diagnostics of the latest --detect-middle scan: out[0] = big tiles (2048 interiors) its bit-sliced adapter scan walked, out[1] = big
 // tiles in all, out[2] = tiles of 128 interiors left to the binary16 kernel, out[3] = tiles of 128 in all (all 0: path not taken)
 extern "C" int qcat_ctx_middle_bitslice_tiles(qcat_ctx* c, uint32_t* out) {
@@ -1055,7 +1056,9 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
     const DevKit& hk = kit->hk.dk;
     std::vector<uint8_t> cat;
     std::vector<uint64_t> cat_off;
-    if (ptrs && (hk.scan_middle || n_reads < 256 || getenv("QCAT_HIP_FULL_UPLOAD"))) {      // the paths that take whole reads: concatenate
+    // (round 5: small batches are compacted into the context's own staging like big ones -- a fresh pair of device buffers per
+    //  call, as before, was two hipMalloc / hipFree and a synchronisation in every single-read call)
+    if (ptrs && (hk.scan_middle || getenv("QCAT_HIP_FULL_UPLOAD"))) {      // the paths that take whole reads: concatenate
         cat_off.resize((size_t)n_reads + 1);
         uint64_t tot = 0;
         for (uint32_t r = 0; r < n_reads; ++r) { cat_off[r] = tot; tot += lens[r]; }
@@ -1064,7 +1067,7 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
         for (uint32_t r = 0; r < n_reads; ++r) if (lens[r]) memcpy(cat.data() + cat_off[r], ptrs[r], (size_t)lens[r]);
         bases = cat.data(); offsets = cat_off.data(); ptrs = nullptr;
     }
-    if (hk.scan_middle || n_reads < 256 || getenv("QCAT_HIP_FULL_UPLOAD"))
+    if (hk.scan_middle || getenv("QCAT_HIP_FULL_UPLOAD"))
         return qcat_batch_upload(c, bases, offsets, n_reads, out);
     if (!c || !out || (!ptrs && (!offsets || (!bases && offsets[n_reads] > 0)))) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
     if (!ptrs && offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
@@ -1494,6 +1497,62 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
     return 0;
 }
 
+// The device work of a host-buffer call -- everything between the upload and the download -- launched kernel by kernel
+// (`enqueue`) or replayed as ONE graph.  A call shaped like the one before it (same kit, read count, compacted bases; nothing
+// reallocated in between) replays: the launches take no arguments from the host but buffer addresses and sizes, every
+// decision that depends on the data (kit vote, job plan, cursors) is made on the device.  The second such call captures
+// (hipStreamBeginCapture, thread-local mode; the side streams join the capture through fork_join's events), later ones
+// replay (`prep`: host-side state a replay needs as well).  QCAT_HIP_NO_GRAPH=1: always launch kernel by kernel.  Timed
+// contexts and the diagnostic switches (they synchronise inside the scan) never capture.  A failure drains the stream before
+// it returns (the upload may still be reading the pinned staging).
+template <class Enqueue, class Prep>
+static int api_graph_run(qcat_ctx* c, qcat_ctx::ApiGraph& G, qcat_kit* kit, KitOnDevice* kd, const qcat_batch* b, uint32_t batch_reads,
+                         Enqueue enqueue, Prep prep) {
+    const uint32_t n_reads = b->n_reads;
+    auto drained = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
+    static const char* const no_capture[] = {"QCAT_HIP_NO_GRAPH", "QCAT_HIP_DEBUG_VOTE", "QCAT_HIP_BS_TRACE", "QCAT_HIP_DEBUG_BINS", "QCAT_HIP_DEBUG_REDO"};
+    bool graph_ok = !c->timing && G.failures < 2 && b->borrowed;      // (whole reads -- --detect-middle -- sit in buffers of their own)
+    for (const char* name : no_capture) if (getenv(name)) graph_ok = false;
+    const uint64_t gen_before = g_alloc_gen.load();
+    bool done = false;
+    int rc = 0;
+    if (graph_ok && G.exec && G.kit == kit->serial && G.n_reads == n_reads && G.n_bases == b->n_bases && G.gen == gen_before && G.batch_reads == batch_reads) {
+        prep();
+        g_jit = kd;
+        HIPCHK_DRAIN(c->stream, hipGraphLaunch(G.exec, c->stream));
+        ++G.replays;
+        done = true;
+    } else if (graph_ok && G.prev_kit == kit->serial && G.prev_reads == n_reads && G.prev_bases == b->n_bases && G.prev_gen == gen_before && G.prev_batch == batch_reads) {
+        if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int erc = enqueue();
+            const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
+            const bool captured = erc == 0 && ee == hipSuccess && graph != nullptr;
+            const bool moved = g_alloc_gen.load() != gen_before;     // (some context allocated meanwhile: not this call's failure)
+            if (captured && !moved && hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                G.kit = kit->serial; G.n_reads = n_reads; G.n_bases = b->n_bases; G.gen = gen_before; G.batch_reads = batch_reads;
+                if (hipGraphLaunch(G.exec, c->stream) == hipSuccess) done = true;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!done && !(captured && moved)) {
+                ++G.failures;
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(c->stream);
+                packed_streams_reset(&c->packed);                // (fresh side streams: the old ones may still think they capture)
+            }
+        } else ++G.failures;
+        if (!done) {                                             // (nothing of the capture ran: the plain launches below do the work)
+            (void)hipGetLastError();
+            if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
+            g_fill_defer = false; g_fill.n = 0;
+        }
+    }
+    if (!done && (rc = enqueue())) return drained(rc);
+    G.prev_kit = kit->serial; G.prev_reads = n_reads; G.prev_bases = b->n_bases; G.prev_gen = g_alloc_gen.load(); G.prev_batch = batch_reads;
+    return 0;
+}
+
 extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
                                const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
                                qcat_result* out, int64_t* counts,
@@ -1510,7 +1569,16 @@ extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
     int rc = batch_upload_windows(c, kit, bases, offsets, n_reads, &b);
     if (rc) return rc;
     const bool debug = traces != nullptr || bc_rows != nullptr;
-    rc = scan_resident_impl(c, kit, b, debug, bc_rows ? row_stride : 0);
+    if (!debug && b->borrowed && n_reads && n_reads <= 65536) {
+        // the reference's library entry -- detect_barcode / detect_barcode_batch with a named kit, down to ONE read per call
+        // (qcat/test/test_barcode.py:84, cli.py:504-509) -- is a dozen launches of a few microseconds each: calls of one shape
+        // replay them as a graph, like the kit-auto calls (api_graph_run)
+        KitOnDevice* kd = nullptr;
+        rc = kit_on_device(kit, c->device, &kd);
+        if (!rc) rc = api_graph_run(c, c->scan_graph, kit, kd, b, 0, [&] { return scan_resident_impl(c, kit, b, false, 0); }, [] {});
+        else (void)hipStreamSynchronize(c->stream);
+        if (!rc) { c->last_n_reads = n_reads; c->last_buckets = kit->hk.dk.n_buckets; }      // (a replay does not pass through scan_resident_impl)
+    } else rc = scan_resident_impl(c, kit, b, debug, bc_rows ? row_stride : 0);
     if (!rc) rc = qcat_ctx_fetch_results(c, out, n_reads);
     if (!rc && counts) {
         std::vector<int64_t> tmp((size_t)kit->hk.dk.n_buckets);
@@ -1642,52 +1710,8 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
         }
         return scan_resident_impl(c, kit, b, false, 0, false, RESUME_KIT_ON_DEVICE);
     };
-    // A call shaped like the one before it (same kit, read count, compacted bases; nothing reallocated in between) replays
-    // that work as ONE graph launch: the launches take no arguments from the host but buffer addresses and sizes, every
-    // decision that depends on the data (kit vote, job plan, cursors) is made on the device.  The second such call captures
-    // (hipStreamBeginCapture, thread-local mode; the side streams join the capture through fork_join's events), later ones
-    // replay.  QCAT_HIP_NO_GRAPH=1: always launch kernel by kernel.  Timed contexts and the diagnostic switches (they
-    // synchronise inside the scan) never capture.
-    qcat_ctx::ApiGraph& G = c->api_graph;
-    static const char* const no_capture[] = {"QCAT_HIP_NO_GRAPH", "QCAT_HIP_DEBUG_VOTE", "QCAT_HIP_BS_TRACE", "QCAT_HIP_DEBUG_BINS", "QCAT_HIP_DEBUG_REDO"};
-    bool graph_ok = !c->timing && G.failures < 2 && b->borrowed;      // (a small batch is uploaded whole into buffers of its own)
-    for (const char* name : no_capture) if (getenv(name)) graph_ok = false;
-    const uint64_t gen_before = g_alloc_gen.load();
-    bool done = false;
-    if (graph_ok && G.exec && G.kit == kit->serial && G.n_reads == n_reads && G.n_bases == b->n_bases && G.gen == gen_before && G.batch_reads == batch_reads) {
-        c->packed.kit_slot_dev = chosen_dev; c->packed.kit_slot_span = slot_span;
-        g_jit = kd;
-        HIPCHK_DRAIN(c->stream, hipGraphLaunch(G.exec, c->stream));
-        ++G.replays;
-        done = true;
-    } else if (graph_ok && G.prev_kit == kit->serial && G.prev_reads == n_reads && G.prev_bases == b->n_bases && G.prev_gen == gen_before && G.prev_batch == batch_reads) {
-        if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            const int erc = enqueue();
-            const hipError_t ee = hipStreamEndCapture(c->stream, &graph);
-            const bool captured = erc == 0 && ee == hipSuccess && graph != nullptr;
-            const bool moved = g_alloc_gen.load() != gen_before;     // (some context allocated meanwhile: not this call's failure)
-            if (captured && !moved && hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                G.kit = kit->serial; G.n_reads = n_reads; G.n_bases = b->n_bases; G.gen = gen_before; G.batch_reads = batch_reads;
-                if (hipGraphLaunch(G.exec, c->stream) == hipSuccess) done = true;
-            }
-            if (graph) (void)hipGraphDestroy(graph);
-            if (!done && !(captured && moved)) {
-                ++G.failures;
-                (void)hipGetLastError();
-                (void)hipStreamSynchronize(c->stream);
-                packed_streams_reset(&c->packed);                // (fresh side streams: the old ones may still think they capture)
-            }
-        } else ++G.failures;
-        if (!done) {                                             // (nothing of the capture ran: the plain launches below do the work)
-            (void)hipGetLastError();
-            if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
-            g_fill_defer = false; g_fill.n = 0;
-        }
-    }
-    if (!done && (rc = enqueue())) return drained(rc);
-    G.prev_kit = kit->serial; G.prev_reads = n_reads; G.prev_bases = b->n_bases; G.prev_gen = g_alloc_gen.load(); G.prev_batch = batch_reads;
+    if ((rc = api_graph_run(c, c->api_graph, kit, kd, b, batch_reads, enqueue,
+                            [&] { c->packed.kit_slot_dev = chosen_dev; c->packed.kit_slot_span = slot_span; }))) return rc;
     unsigned long long hv[MAX_T], hf[MAX_T];
     std::vector<int32_t> chosen((size_t)nb, -1);
     std::vector<int64_t> tmp(counts ? (size_t)hk.n_buckets : 0);

@@ -68,3 +68,36 @@ def test_scan_middle_with_unknown_kit_raises_like_the_reference():
     det = scanner.factory(kit="PBC096")
     with pytest.raises(IndexError):
         det.scan_middle("ACGT" * 200, "no-such-kit", config.qcatConfig())
+
+
+@pytest.mark.parametrize("mode,kit", [("epi2me", "PBC096"), ("epi2me", "RBK004"), ("dual", None)])
+def test_single_read_calls_of_one_shape_replay_a_captured_graph(mode, kit, monkeypatch):
+    """Round 5: detect_barcode on ONE read per call -- the reference's library entry (qcat/test/test_barcode.py:84; the driver's
+    --no-batch loop, cli.py:504-509) -- with a named kit: calls of one shape (same kit, one read, the same compacted size)
+    replay the first such call's launches as a graph (qcat_scan_batch -> api_graph_run).  Every call's record must be the
+    oracle's whatever ran before it: other reads, a read of another size (which neither replays nor disturbs the graph), a
+    batch call in between."""
+    det = scanner.factory(mode=mode, kit=kit)
+    lays = det.layouts
+    t5, t3 = (1, 0) if len(lays) > 1 else (0, -1)
+    reads = synth.synth_batch(60, 4242, lays, t5, t3, error_rate=0.08)
+    reads[7] = reads[7][:220]                                  # (shorter than two windows: another compacted size)
+    reads[8] = ""
+    reads[9] = reads[9][:40]
+    d = det.descriptor(ends=native.ENDS_BOTH)
+    want = oracle_lib.scan(d, reads, threads=4)
+    kit_h = native.NativeKit(d)
+    ctx = native.NativeContext(0)
+    lib = native.HipLibrary.get().lib
+    before = lib.qcat_ctx_graph_replays(ctx.handle)
+    for i, r in enumerate(reads):
+        got = ctx.scan(kit_h, *native.pack_reads([r]))
+        assert got.tobytes() == want[i:i + 1].tobytes(), i
+        if i == 30:                                            # a batch of another shape between the single reads
+            assert ctx.scan(kit_h, *native.pack_reads(reads[:20])).tobytes() == want[:20].tobytes()
+    assert lib.qcat_ctx_graph_replays(ctx.handle) - before >= 40
+    monkeypatch.setenv("QCAT_HIP_NO_GRAPH", "1")
+    off = lib.qcat_ctx_graph_replays(ctx.handle)
+    for i in (3, 4, 5):
+        assert ctx.scan(kit_h, *native.pack_reads([reads[i]])).tobytes() == want[i:i + 1].tobytes()
+    assert lib.qcat_ctx_graph_replays(ctx.handle) == off

@@ -1,0 +1,25 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+out=$R/gpurun_out/r05_api1
+mkdir -p $out
+rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/rp_api1 -o t --output-format csv -- python $R/bench.py --workload api1 --steps 1 --reads 300 > $out/trace_run.log 2>&1
+ls /tmp/rp_api1/*/ | head
+python - <<'PY'
+import csv, glob
+k = glob.glob('/tmp/rp_api1/**/*kernel_trace.csv', recursive=True)[0]
+m = glob.glob('/tmp/rp_api1/**/*memory_copy_trace.csv', recursive=True)[0]
+ev = []
+for r in csv.DictReader(open(k)):
+    ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'][:60]))
+for r in csv.DictReader(open(m)):
+    ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r.get('Direction', r.get('Name', ''))[:40] ))
+ev.sort()
+# the last named-kit call: find a window of events near 60% of the run
+n = len(ev)
+i0 = n // 3
+# print 60 consecutive events with gaps
+t0 = ev[i0][0]
+for s, e, name in ev[i0:i0 + 70]:
+    print("%9.1f us  +%7.1f us  %s" % ((s - t0) / 1e3, (e - s) / 1e3, name))
+PY
