@@ -399,6 +399,25 @@ int  qcat_ctx_last_timing(qcat_ctx* ctx, const char** names, float* ms, int cap)
  * a few microseconds per launch). */
 int  qcat_ctx_set_timing(qcat_ctx* ctx, int enabled);
 
+/* ---- options (ABI 5) ----
+ * The library's tuning / diagnostic switches (csrc/options.h holds the table with one line of description each;
+ * qcat_option_count / _name / _doc enumerate it).  They are process-wide.  None changes a result: they move work between
+ * kernels that give identical records, size buffers or print diagnostics -- the tests flip them to cross-check the device
+ * paths.  The environment variable QCAT_HIP_<NAME> is read ONCE, when the library is loaded; afterwards an option only
+ * changes through these calls (`name` with or without the QCAT_HIP_ prefix).  A flag is on when it is set and not 0.
+ * qcat_get_option returns 1 / 0 for set / not set (negative: no such option); qcat_reset_options goes back to the
+ * environment's values. */
+int  qcat_set_option(const char* name, int64_t value);
+int  qcat_clear_option(const char* name);
+int  qcat_get_option(const char* name, int64_t* value);
+void qcat_reset_options(void);
+int  qcat_option_count(void);
+const char* qcat_option_name(int index);
+const char* qcat_option_doc(int index);
+/* "hip" for this library.  (The CPU oracle behind the same ABI -- test infrastructure, oracle/qcat_cpu_abi.c -- answers
+ * "cpu-oracle": the Python host refuses to run a product path on it.) */
+const char* qcat_backend(void);
+
 /* ---- native FASTQ ingest and egress (SURVEY.md 8f rank 2 at speed) ----
  * replaces: the per-file loop of the reference driver, qcat/cli.py:445-563 -- iter_fastx over FastqGeneralIterator
  * (:235-306), detect_barcode_batch per batch of 4000 reads (:500-513), trimming (:521-526), the minimum-length filter

@@ -36,6 +36,7 @@ struct qcat_ctx { int device; int threads; };
 
 const char* qcat_last_error(void) { return cpu_err[0] ? cpu_err : qo_last_error(); }
 int qcat_abi_version(void) { return QCAT_ABI_VERSION; }
+const char* qcat_backend(void) { return "cpu-oracle"; }      /* (the product's loader refuses anything but "hip": qcat_amd/native.py) */
 int qcat_device_count(void) { return 0; }
 
 int qcat_kit_create(const qcat_kit_desc* desc, qcat_kit** out) {

@@ -17,6 +17,7 @@
 #endif
 
 #include "../../include/qcat_hip.h"
+#include "options.h"
 
 namespace qk {
 

@@ -76,7 +76,7 @@ static PyObject* records_to_dicts(PyObject* self, PyObject* args) {
         /* the same IEEE double expression as qcat/scanner_base.py:119: raw * 100.0 / (1.0 * den) */
         const double den = r[i].score_den > 1 ? (double)r[i].score_den : 1.0;
         const double score = b > 0 ? (double)r[i].raw_score * 100.0 / (1.0 * den) : 0.0;
-        PyObject* d = _PyDict_NewPresized(7);            /* (seven keys: no resize on the way) */
+        PyObject* d = PyDict_New();            
         PyObject* v_score = PyFloat_FromDouble(score);
         PyObject* v_end = PyLong_FromLong(r[i].adapter_end);
         PyObject* v_t5 = PyLong_FromLong(r[i].trim5p);

@@ -63,6 +63,60 @@ static int set_err(int rc, const std::string& m) { g_err = m; return rc; }
 
 extern "C" const char* qcat_last_error(void) { return g_err.c_str(); }
 extern "C" int qcat_abi_version(void) { return QCAT_ABI_VERSION; }
+extern "C" const char* qcat_backend(void) { return "hip"; }
+
+// ------------------------------------------------------------------------------------------
+// options (options.h): the table, its one import from the environment, the ABI around it
+// ------------------------------------------------------------------------------------------
+std::atomic<int64_t> g_qcat_opt[QO_COUNT];
+static const char* const g_qcat_opt_name[QO_COUNT] = {
+#define X(N, D) #N,
+    QCAT_OPTION_LIST(X)
+#undef X
+};
+static const char* const g_qcat_opt_doc[QO_COUNT] = {
+#define X(N, D) D,
+    QCAT_OPTION_LIST(X)
+#undef X
+};
+static void qcat_options_from_env() {
+    for (int i = 0; i < QO_COUNT; ++i) {
+        const std::string env = std::string("QCAT_HIP_") + g_qcat_opt_name[i];
+        const char* e = getenv(env.c_str());                        // (the library's only look at QCAT_HIP_* switches: once, here)
+        g_qcat_opt[i].store(e ? (*e ? (int64_t)atoll(e) : 1) : QOPT_UNSET, std::memory_order_relaxed);
+    }
+}
+static struct QcatOptInit { QcatOptInit() { qcat_options_from_env(); } } g_qcat_opt_init;
+static int qcat_opt_index(const char* name) {
+    if (!name) return -1;
+    if (strncmp(name, "QCAT_HIP_", 9) == 0) name += 9;
+    for (int i = 0; i < QO_COUNT; ++i) if (strcmp(name, g_qcat_opt_name[i]) == 0) return i;
+    return -1;
+}
+extern "C" int qcat_option_count(void) { return QO_COUNT; }
+extern "C" const char* qcat_option_name(int i) { return i >= 0 && i < QO_COUNT ? g_qcat_opt_name[i] : nullptr; }
+extern "C" const char* qcat_option_doc(int i) { return i >= 0 && i < QO_COUNT ? g_qcat_opt_doc[i] : nullptr; }
+extern "C" void qcat_reset_options(void) { qcat_options_from_env(); }
+extern "C" int qcat_set_option(const char* name, int64_t value) {
+    const int i = qcat_opt_index(name);
+    if (i < 0) return set_err(QCAT_ERR_ARG, std::string("qcat_set_option: no option named ") + (name ? name : "(null)"));
+    if (value == QOPT_UNSET) return set_err(QCAT_ERR_ARG, "qcat_set_option: the value INT64_MIN means unset (qcat_clear_option)");
+    g_qcat_opt[i].store(value, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int qcat_clear_option(const char* name) {
+    const int i = qcat_opt_index(name);
+    if (i < 0) return set_err(QCAT_ERR_ARG, std::string("qcat_clear_option: no option named ") + (name ? name : "(null)"));
+    g_qcat_opt[i].store(QOPT_UNSET, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int qcat_get_option(const char* name, int64_t* value) {          // returns 1 when the option is set (*value), 0 when it is not
+    const int i = qcat_opt_index(name);
+    if (i < 0) return set_err(QCAT_ERR_ARG, std::string("qcat_get_option: no option named ") + (name ? name : "(null)"));
+    const int64_t v = g_qcat_opt[i].load(std::memory_order_relaxed);
+    if (value) *value = v == QOPT_UNSET ? 0 : v;
+    return v == QOPT_UNSET ? 0 : 1;
+}
 extern "C" int qcat_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -485,8 +539,8 @@ extern "C" int qcat_ctx_create(int device, qcat_ctx** out) {
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return set_err(QCAT_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
-    const char* fg = getenv("QCAT_HIP_FORCE_GENERIC");
-    c->force_generic = (fg && fg[0] == '1') ? 1 : 0;
+    const QOptVal fg = qopt_get(QO_FORCE_GENERIC);
+    c->force_generic = (fg && fg.v == 1) ? 1 : 0;
     *out = c;
     return 0;
 }
@@ -554,7 +608,7 @@ static void mark(qcat_ctx* c, const char* name) {
 // packed --detect-middle is possible when every template has a generated static-letter adapter
 // kernel (all built-in kits) and the kit's slots fit the sort tables
 static bool middle_packed_ok(const DevKit& hk) {
-    if (!hk.adapter_f16 || hk.n_kit_slots > MID_MAX_KITS || getenv("QCAT_HIP_MIDDLE_GENERIC")) return false;
+    if (!hk.adapter_f16 || hk.n_kit_slots > MID_MAX_KITS || opt_on(QO_MIDDLE_GENERIC)) return false;
     // the interior kernel carries up to PK_ROWS + 63 rows of bias inside a block plus the offset of its
     // last-row keys (kernels_middle.inc): g * ((152 + 63 + 128 + 64) - (160 + 128)) + 1 more than a window
     if (hk.adapter_f16_headroom < hk.gap_open * 119 + 1) return false;
@@ -583,11 +637,11 @@ static size_t middle_slots(const DevKit& hk, uint32_t n) {
     return ((size_t)2 * n + (size_t)hk.n_kit_slots * MID_CLASSES * PK_TILE + PK_TILE - 1) / PK_TILE * PK_TILE;
 }
 static uint32_t absmid_wanted(const DevKit& hk, uint32_t n) {
-    const char* amin = getenv("QCAT_HIP_MIDDLE_ABS_MIN");
+    const QOptVal amin = qopt_get(QO_MIDDLE_ABS_MIN);
     // from 1.25 big tiles of 2048 slots per CU (330 k reads on 256 CUs): below that the binary16 kernel's 3 us per thousand interiors
     // beat a tile's sequential walk (tools/r04_absmid_sizes.sh, profiles/r04_ab_absmid_sizes.txt)
     const size_t min_slots = amin ? (size_t)atoll(amin) : (size_t)abs_cu_count() * 2048 * 5 / 4;
-    if (getenv("QCAT_HIP_MIDDLE_NO_ABS") || middle_slots(hk, n) < min_slots) return 0u;
+    if (opt_on(QO_MIDDLE_NO_ABS) || middle_slots(hk, n) < min_slots) return 0u;
     return absmid_kit_mask(hk);
 }
 constexpr size_t ABSM_C2_SLACK_HOST = 1040;                                     // = ABSM_C2_SLACK (kernels_abs_mid.inc)
@@ -598,7 +652,7 @@ constexpr size_t ABSM_C2_SLACK_HOST = 1040;                                     
 // the read ends -- bound by memory themselves -- gain 0.08 + 0.06 ms: 5.14 ms per step either way.
 static int absmid_codes_early(qcat_ctx* c, const DevKit& hk, const qcat_batch* b, uint32_t n) {
     c->absm_codes_early = false;
-    if (!(getenv("QCAT_HIP_MIDDLE_ABS_EARLY") && atoi(getenv("QCAT_HIP_MIDDLE_ABS_EARLY")) == 1)) return 0;
+    if (!((opt_is_set(QO_MIDDLE_ABS_EARLY) && opt_val(QO_MIDDLE_ABS_EARLY, 0) == 1))) return 0;
     if (!absmid_wanted(hk, n)) return 0;
     int rc;
     if (!c->absm_stream) {
@@ -659,7 +713,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     PackedScratch* sc = &c->packed;
     // round 4: the interiors' first window at two bits per code, so that their whole-window barcode jobs -- nearly all of
     // them -- run on the bit-sliced barcode kernels (QCAT_HIP_MIDDLE_NO_BITSLICE=1: binary16 kernels as before)
-    const bool mid_bs = getenv("QCAT_HIP_MIDDLE_NO_BITSLICE") == nullptr;
+    const bool mid_bs = !opt_on(QO_MIDDLE_NO_BITSLICE);
     // (with the bit-sliced adapter scan below the windows come from its packed batch instead: k_absmid_windows.  k_mid_windows beside
     //  the adapter kernels was measured and lost: those fill the register files, each of their waves walks ONE tile, and a wave that
     //  starts late is the kernel's tail; beside the preparation chain -- kernels that wait for memory like itself -- it gained 0.02 ms)
@@ -687,9 +741,16 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             const uint32_t big = (uint32_t)((slots + 2047) / 2048);
             // rows of all big tiles together: every tile as long as its longest interior -- the mean of the interiors plus
             // the width of the length classes a tile spans; a tile beyond the room falls back to the binary16 kernel
-            const char* rcap = getenv("QCAT_HIP_MIDDLE_ABS_ROWS");         // (tests: a plane buffer that is too small)
-            const size_t rows = rcap ? (size_t)atoll(rcap)
-                                     : std::min<size_t>((size_t)1 << 30, (size_t)(2 * b->n_bases / 2048) * 5 / 4 + (size_t)big * 128 + 16384 + 64);
+            const QOptVal rcap = qopt_get(QO_MIDDLE_ABS_ROWS);         // (tests: a plane buffer that is too small)
+            size_t rows = rcap ? (size_t)atoll(rcap)
+                               : std::min<size_t>((size_t)1 << 30, (size_t)(2 * b->n_bases / 2048) * 5 / 4 + (size_t)big * 128 + 16384 + 64);
+            if (!rcap && rows * 64 > c->cap_absm_planes) {
+                // planes + not-started masks are 768 bytes per row (~0.9 bytes per base of the batch): never more than a quarter
+                // of the device memory that is free right now -- the big tiles beyond the room fall back to the binary16 kernel
+                // per tile (k_absmid_scan: row_cap), which needs none of it
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) rows = std::min(rows, std::max<size_t>(16384, free_b / 4 / 768));
+            }
             const size_t tw = (size_t)big * (4 + 128) + MAX_T;
             if ((rc = grow(&c->absm_tiles, &c->cap_absm_tiles, tw))) return rc;
             if ((rc = grow(&c->absm_need, &c->cap_absm_need, (size_t)tiles + 16))) return rc;
@@ -716,11 +777,11 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             am.bests = c->mid_bests; am.tpl = -1; am.den = 0; am.kit_slot = -1;
             // issue priority of the row loops rotated every two rows by workgroup parity (abs_setprio; two waves of different
             // launches share a SIMD): 4.79 against 4.91 ms per step at 1 M reads (tools/r04_absmid_prio.sh); QCAT_HIP_MIDDLE_ABS_PRIO
-            const char* pr = getenv("QCAT_HIP_MIDDLE_ABS_PRIO") ? getenv("QCAT_HIP_MIDDLE_ABS_PRIO") : getenv("QCAT_HIP_ABS_PRIO");
+            const QOptVal pr = opt_is_set(QO_MIDDLE_ABS_PRIO) ? qopt_get(QO_MIDDLE_ABS_PRIO) : qopt_get(QO_ABS_PRIO);
             am.prio = pr ? atoi(pr) : 2;
             HIPCHK(hipMemsetAsync(am.cursor, 0, MAX_T * 4, st));
             // the M-ends' first windows (k_mid_windows) come from the packed batch too: QCAT_HIP_MIDDLE_ABS_WINDOWS=0: from the reads, beside
-            const bool c2win = mid_bs && !(getenv("QCAT_HIP_MIDDLE_ABS_WINDOWS") && atoi(getenv("QCAT_HIP_MIDDLE_ABS_WINDOWS")) == 0);
+            const bool c2win = mid_bs && !((opt_is_set(QO_MIDDLE_ABS_WINDOWS) && opt_val(QO_MIDDLE_ABS_WINDOWS, 0) == 0));
             fork_join(sc, st, (mid_bs && !c2win) ? 2 : 1, [&](int i, hipStream_t q) {
                 if (i == 0) qcat_absmid_prepare(q, &am, c2win ? c->mid_win2 : nullptr, c2win ? c->mid_wspec : nullptr, early ? 2 : 3); else launch_mid_windows(q);
             });
@@ -740,8 +801,8 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             // two launches of four per CU each do not fit the register file together, and the second one then runs after
             // the first (1.2 + 0.6 ms at 1 M reads against ~1.0 ms side by side).  QCAT_HIP_MIDDLE_ABS_WGS=<per CU and launch>
             // A template of up to 46 columns walks a tile on ONE wave (k_adapter_mid1: eight per CU); QCAT_HIP_MIDDLE_ABS_ONE_WAVE=0 / 1: pipeline / one wave whatever the size.
-            const char* wg = getenv("QCAT_HIP_MIDDLE_ABS_WGS");
-            const char* ow = getenv("QCAT_HIP_MIDDLE_ABS_ONE_WAVE");
+            const QOptVal wg = qopt_get(QO_MIDDLE_ABS_WGS);
+            const QOptVal ow = qopt_get(QO_MIDDLE_ABS_ONE_WAVE);
             const int sk = hk.tpl[t].static_kernel;
             // one wave per tile from 2.75 big tiles per CU (720 k reads): with fewer tiles than wave slots a tile's walk is the kernel,
             // and the pipeline's two waves halve it (400 k reads: interior phase 1.95 against 2.29 ms; 800 k: 2.96 against 2.87)
@@ -814,7 +875,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     // the fills of a scan leave as ONE launch in front of the pack kernel (k_fill_multi): count vector, letter flags, and --
     // with the job tables and the adapter tile flags sized here instead of after the pack kernel -- theirs too
     const bool use_packed = hk.fast_ok && !c->force_generic && packed_supported(hk);
-    g_fill_defer = n != 0 && getenv("QCAT_HIP_NO_FILL_MERGE") == nullptr;
+    g_fill_defer = n != 0 && !opt_on(QO_NO_FILL_MERGE);
     if (!keep_counts) HIPCHK(packed_fill(c->counts, 0, (size_t)hk.n_buckets * 8, c->stream));
     if (n == 0) { HIPCHK(packed_fill_flush(c->stream)); return 0; }
     if (c->timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));   // (an empty batch returned above: its slot holds no marks)
@@ -830,14 +891,14 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         HIPCHK(packed_fill(c->wspec, 0, n_ends, c->stream));
         c->packed.abs_ready = 0;
         if (g_fill_defer && use_packed && hk.mode != QCAT_MODE_SIMPLE) {
-            c->packed.slim = use_packed && !debug && getenv("QCAT_HIP_NO_SLIM") == nullptr;     // (packed_prepare sizes the slim buffers)
+            c->packed.slim = use_packed && !debug && !opt_on(QO_NO_SLIM);     // (packed_prepare sizes the slim buffers)
             if ((rc = packed_prepare(c->stream, hk, (uint32_t)n_ends, &c->packed))) { g_fill_defer = false; g_fill.n = 0; return set_err(rc, packed_last_error()); }
             c->packed.prepared = true;
-            if (getenv("QCAT_HIP_PACK_PLANES") == nullptr && packed_abs_wanted(hk, (uint32_t)n_ends, true) &&
+            if (!opt_on(QO_PACK_PLANES) && packed_abs_wanted(hk, (uint32_t)n_ends, true) &&
                 (rc = packed_abs_buffers(c->stream, hk, (uint32_t)n_ends, &c->packed))) { g_fill_defer = false; g_fill.n = 0; return set_err(rc, packed_last_error()); }
         }
         HIPCHK(packed_fill_flush(c->stream));
-        if (use_packed && hk.mode != QCAT_MODE_SIMPLE && getenv("QCAT_HIP_PACK_PLANES") != nullptr && packed_abs_wanted(hk, (uint32_t)n_ends, true)) {
+        if (use_packed && hk.mode != QCAT_MODE_SIMPLE && opt_on(QO_PACK_PLANES) && packed_abs_wanted(hk, (uint32_t)n_ends, true)) {
             // (A/B switch, off by default) the windows and their letter planes in one pass (kernels_abs.inc: k_pack_planes).
             // Measured and dropped: 5.1 ms against 1.67 + 0.85 ms for k_pack_windows + k_abs_planes on config 3 -- a wave that
             // walks eight slices of 640 items serially is latency-bound on the offsets -> bases load chains, where
@@ -856,8 +917,8 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
             // lazy byte windows (round 4): a kit whose every template runs a generated kernel reads plain windows at two
             // bits per code everywhere (dev_window16), so the byte windows -- 3.3 of the pack kernel's 4.1 GB of stores per
             // 10 M reads -- are written for the flagged ends only (k_expand_special; QCAT_HIP_EAGER_BYTES=1: all of them)
-            bool lazy = use_packed && hk.mode != QCAT_MODE_SIMPLE && hk.adapter_f16 && getenv("QCAT_HIP_NO_STATIC") == nullptr &&
-                        getenv("QCAT_HIP_NO_STATIC_ADAPTER") == nullptr && getenv("QCAT_HIP_EAGER_BYTES") == nullptr;
+            bool lazy = use_packed && hk.mode != QCAT_MODE_SIMPLE && hk.adapter_f16 && !opt_on(QO_NO_STATIC) &&
+                        !opt_on(QO_NO_STATIC_ADAPTER) && !opt_on(QO_EAGER_BYTES);
             for (int t = 0; t < hk.nt && lazy; ++t) lazy = hk.tpl[t].static_kernel >= 0;
             c->packed.lazy = lazy;
             hipLaunchKernelGGL(k_pack_windows, dim3(blocks), dim3(256), 0, c->stream,
@@ -869,7 +930,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     }
     if (resume_kit_mask >= 0 && g_fill_defer && use_packed && c->packed.slices_single && hk.mode != QCAT_MODE_SIMPLE) {
         // (a resumed scan -- the second pass of a kit-auto batch: its job tables' fills with the count vector's, one launch)
-        c->packed.slim = use_packed && !debug && getenv("QCAT_HIP_NO_SLIM") == nullptr;
+        c->packed.slim = use_packed && !debug && !opt_on(QO_NO_SLIM);
         if ((rc = packed_prepare(c->stream, hk, (uint32_t)n_ends, &c->packed))) { g_fill_defer = false; g_fill.n = 0; return set_err(rc, packed_last_error()); }
         c->packed.prepared = true;
     }
@@ -880,7 +941,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     c->packed.wspec = c->wspec; c->packed.win = c->win; c->packed.win2 = c->win2_valid ? c->win2 : nullptr;
     // packed barcode results (kernels_bitslice.inc: k_bs_select_ordered) instead of 8 bytes scattered into every record;
     // debug scans keep the records complete for the traces
-    const bool slim = use_packed && !debug && hk.mode != QCAT_MODE_SIMPLE && getenv("QCAT_HIP_NO_SLIM") == nullptr;
+    const bool slim = use_packed && !debug && hk.mode != QCAT_MODE_SIMPLE && !opt_on(QO_NO_SLIM);
     c->packed.slim = slim;
     if (hk.mode == QCAT_MODE_SIMPLE) {
         uint32_t blocks = (uint32_t)((n_ends + GEN_THREADS - 1) / GEN_THREADS);
@@ -904,7 +965,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         // every block zeroes and flushes an LDS histogram of n_buckets entries with global atomics on the same few counters:
         // fewer, fatter blocks -- 1024 (measured, tools/r04_fin.sh: config 2 0.059 -> 0.028 ms against 4096 blocks, config 3
         // 0.235 -> 0.207 ms), 512 when the bucket vector is long (dual kits: 0.052 against 0.072 ms)
-        const char* fb_env = getenv("QCAT_HIP_FIN_BLOCKS");                          // (A/B runs)
+        const QOptVal fb_env = qopt_get(QO_FIN_BLOCKS);                          // (A/B runs)
         uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, fb_env ? (uint64_t)std::max(1, atoi(fb_env)) : (hk.n_buckets > 2048 ? 512 : 1024));
         const bool middle = hk.scan_middle != 0;
         hipLaunchKernelGGL(k_finalize, dim3(blocks), dim3(256), fin_lds_bytes(hk.n_buckets, !middle), c->stream,
@@ -1058,16 +1119,20 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
     std::vector<uint64_t> cat_off;
     // (round 5: small batches are compacted into the context's own staging like big ones -- a fresh pair of device buffers per
     //  call, as before, was two hipMalloc / hipFree and a synchronisation in every single-read call)
-    if (ptrs && (hk.scan_middle || getenv("QCAT_HIP_FULL_UPLOAD"))) {      // the paths that take whole reads: concatenate
+    if (ptrs && (hk.scan_middle || opt_on(QO_FULL_UPLOAD))) {      // the paths that take whole reads: concatenate
         cat_off.resize((size_t)n_reads + 1);
         uint64_t tot = 0;
-        for (uint32_t r = 0; r < n_reads; ++r) { cat_off[r] = tot; tot += lens[r]; }
+        for (uint32_t r = 0; r < n_reads; ++r) {
+            if (lens[r] && !ptrs[r]) return set_err(QCAT_ERR_ARG, "null read pointer");
+            if (lens[r] > 0xFFFFFFFFull) return set_err(QCAT_ERR_UNSUPPORTED, "read longer than 4 Gb");
+            cat_off[r] = tot; tot += lens[r];
+        }
         cat_off[n_reads] = tot;
         cat.resize((size_t)tot + 1);
         for (uint32_t r = 0; r < n_reads; ++r) if (lens[r]) memcpy(cat.data() + cat_off[r], ptrs[r], (size_t)lens[r]);
         bases = cat.data(); offsets = cat_off.data(); ptrs = nullptr;
     }
-    if (hk.scan_middle || getenv("QCAT_HIP_FULL_UPLOAD"))
+    if (hk.scan_middle || opt_on(QO_FULL_UPLOAD))
         return qcat_batch_upload(c, bases, offsets, n_reads, out);
     if (!c || !out || (!ptrs && (!offsets || (!bases && offsets[n_reads] > 0)))) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
     if (!ptrs && offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
@@ -1303,7 +1368,7 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
                                 uint32_t n_reads, qcat_result* out, int64_t* counts) {
     const DevKit& hk = kit->hk.dk;
     const uint8_t* bases = rv.bases;
-    if (hk.scan_middle || n_reads < 32768 || getenv("QCAT_HIP_FULL_UPLOAD") || getenv("QCAT_HIP_NO_PIPELINE")) return 1;
+    if (hk.scan_middle || n_reads < 32768 || opt_on(QO_FULL_UPLOAD) || opt_on(QO_NO_PIPELINE)) return 1;
     if (!rv.recs) {
         if (!bases && rv.offsets[n_reads] > 0) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
         if (rv.offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
@@ -1331,7 +1396,7 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
     // chunks of 256 k .. 1 M reads (a quarter of the batch): big enough to fill the chip (1 000+ tiles of 128
     // alignments), small enough that the first chunk's compaction and the last chunk's scan -- the only
     // stages nothing overlaps -- are a small part of the call
-    const char* ce = getenv("QCAT_HIP_PIPELINE_CHUNK");
+    const QOptVal ce = qopt_get(QO_PIPELINE_CHUNK);
     // (heavier per-chunk launches lose less to the tails of the persistent barcode kernels: large batches take 1 M-read chunks)
     // (a chunk costs ~0.3 ms of host time in launches and copies whatever its size: 1 M reads of a small kit run
     // 166 M reads/s in four chunks, 137 M in eight, 97 M in sixteen)
@@ -1382,7 +1447,7 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
         ~TimingOff() { c->timing = was; }
     } timing_off(c);
     int rc = 0;
-    const bool trace = getenv("QCAT_HIP_PIPELINE_TRACE") != nullptr;
+    const bool trace = opt_on(QO_PIPELINE_TRACE);
     double t_wait = 0, t_prefix = 0, t_compact = 0, t_enqueue = 0;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
@@ -1510,9 +1575,9 @@ static int api_graph_run(qcat_ctx* c, qcat_ctx::ApiGraph& G, qcat_kit* kit, KitO
                          Enqueue enqueue, Prep prep) {
     const uint32_t n_reads = b->n_reads;
     auto drained = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
-    static const char* const no_capture[] = {"QCAT_HIP_NO_GRAPH", "QCAT_HIP_DEBUG_VOTE", "QCAT_HIP_BS_TRACE", "QCAT_HIP_DEBUG_BINS", "QCAT_HIP_DEBUG_REDO"};
+    static const QcatOpt no_capture[] = {QO_NO_GRAPH, QO_DEBUG_VOTE, QO_BS_TRACE, QO_DEBUG_BINS, QO_DEBUG_REDO};
     bool graph_ok = !c->timing && G.failures < 2 && b->borrowed;      // (whole reads -- --detect-middle -- sit in buffers of their own)
-    for (const char* name : no_capture) if (getenv(name)) graph_ok = false;
+    for (QcatOpt o : no_capture) if (opt_on(o)) graph_ok = false;
     const uint64_t gen_before = g_alloc_gen.load();
     bool done = false;
     int rc = 0;
@@ -1579,6 +1644,7 @@ extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
         else (void)hipStreamSynchronize(c->stream);
         if (!rc) { c->last_n_reads = n_reads; c->last_buckets = kit->hk.dk.n_buckets; }      // (a replay does not pass through scan_resident_impl)
     } else rc = scan_resident_impl(c, kit, b, debug, bc_rows ? row_stride : 0);
+    if (rc) (void)hipStreamSynchronize(c->stream);          // (the upload may still be reading the context's pinned staging)
     if (!rc) rc = qcat_ctx_fetch_results(c, out, n_reads);
     if (!rc && counts) {
         std::vector<int64_t> tmp((size_t)kit->hk.dk.n_buckets);
@@ -1615,10 +1681,13 @@ static int vote_buffer(qcat_ctx* c, size_t nb) {
 static int vote_resident(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, unsigned long long* hv, unsigned long long* hf) {
     for (int t = 0; t < MAX_T; ++t) { hv[t] = 0; hf[t] = ~0ull; }
     int rc = scan_resident_impl(c, kit, b, false, 0, true);
-    if (rc || !b->n_reads) return rc;
+    // (a failed step drains the stream before it returns: the caller's upload may still be reading the pinned staging)
+    auto drained = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
+    if (rc) return drained(rc);
+    if (!b->n_reads) return 0;
     KitOnDevice* kd = nullptr;
-    if ((rc = kit_on_device(kit, c->device, &kd))) return rc;
-    if ((rc = vote_buffer(c, 1))) return rc;
+    if ((rc = kit_on_device(kit, c->device, &kd))) return drained(rc);
+    if ((rc = vote_buffer(c, 1))) return drained(rc);
     unsigned long long* d = c->vote_buf;
     HIPCHK(hipMemsetAsync(d, 0, MAX_T * 8, c->stream));
     HIPCHK(hipMemsetAsync(d + MAX_T, 0xFF, MAX_T * 8, c->stream));
@@ -1699,7 +1768,7 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
         // pass 2: detect_barcode per read with the voted kit's templates (:714-733): the adapter alignments of the vote are
         // still on the device -- only their merge (the kit slot read from chosen_dev), the barcode phase and the finalisation run now
         c->packed.kit_slot_dev = chosen_dev; c->packed.kit_slot_span = slot_span;
-        if (getenv("QCAT_HIP_DEBUG_VOTE")) {                  // (diagnostics: the choice as the device made it, before the second pass)
+        if (opt_on(QO_DEBUG_VOTE)) {                  // (diagnostics: the choice as the device made it, before the second pass)
             unsigned long long dv[2 * MAX_T]; int32_t dc = -7;
             (void)hipStreamSynchronize(c->stream);
             (void)hipMemcpy(dv, d, sizeof dv, hipMemcpyDeviceToHost);

@@ -289,6 +289,14 @@ class HipLibrary(object):
         sig = {
             "qcat_last_error": (C.c_char_p, []),
             "qcat_abi_version": (C.c_int, []),
+            "qcat_backend": (C.c_char_p, []),
+            "qcat_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+            "qcat_clear_option": (C.c_int, [C.c_char_p]),
+            "qcat_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
+            "qcat_reset_options": (None, []),
+            "qcat_option_count": (C.c_int, []),
+            "qcat_option_name": (C.c_char_p, [C.c_int]),
+            "qcat_option_doc": (C.c_char_p, [C.c_int]),
             "qcat_device_count": (C.c_int, []),
             "qcat_device_numa_node": (C.c_int, [C.c_int]),
             "qcat_kit_create": (C.c_int, [C.POINTER(KitDesc), C.POINTER(vp)]),
@@ -345,6 +353,12 @@ class HipLibrary(object):
             fn = getattr(lib, name)          # AttributeError here = ABI symbol missing
             fn.restype = res
             fn.argtypes = args
+        # QCAT_HIP_LIBRARY may name another BUILD of this library (A/B runs), never another implementation of the ABI: the CPU
+        # oracle behind the same entry points (oracle/libqcat_cpu.so, test infrastructure) answers "cpu-oracle"
+        backend = (lib.qcat_backend() or b"").decode()
+        if backend != "hip" or lib.qcat_abi_version() != ABI_VERSION:
+            raise RuntimeError("qcat_amd: {} is not the HIP library of ABI {} (backend {!r}, ABI {}); there is no CPU fallback"
+                               .format(path, ABI_VERSION, backend, lib.qcat_abi_version()))
         self.lib = lib
         self.path = path
         self.symbols = sorted(sig)
@@ -361,6 +375,38 @@ class HipLibrary(object):
             if rc == -5:                                  # QCAT_ERR_IO: an output of qcat_fastq_demux could not be written
                 raise IOError("qcat_hip: {}".format((msg or b"").decode("utf-8", "replace")))
             raise RuntimeError("qcat_hip error {}: {}".format(rc, (msg or b"").decode("utf-8", "replace")))
+
+
+def set_option(name, value=1):
+    """qcat_set_option: one of the library's process-wide tuning / diagnostic switches (csrc/options.h; ``name`` with or
+    without the QCAT_HIP_ prefix).  ``None`` clears it."""
+    hip = HipLibrary.get()
+    if value is None:
+        hip.check(hip.lib.qcat_clear_option(name.encode()))
+    else:
+        hip.check(hip.lib.qcat_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    """the option's value, or None when it is not set"""
+    hip = HipLibrary.get()
+    v = C.c_int64()
+    rc = hip.lib.qcat_get_option(name.encode(), C.byref(v))
+    if rc < 0:
+        hip.check(rc)
+    return int(v.value) if rc == 1 else None
+
+
+def reset_options():
+    """back to what the environment said when the library was loaded"""
+    HipLibrary.get().lib.qcat_reset_options()
+
+
+def options():
+    """{name: (value or None, description)} of every option"""
+    lib = HipLibrary.get().lib
+    return {lib.qcat_option_name(i).decode(): (get_option(lib.qcat_option_name(i).decode()), lib.qcat_option_doc(i).decode())
+            for i in range(lib.qcat_option_count())}
 
 
 class NativeKit(object):

@@ -32,3 +32,77 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---- the library's switches are options behind the C ABI, not environment variables (csrc/options.h, round 5) -----------------
+# The library reads QCAT_HIP_<NAME> once, when it is loaded; afterwards a switch only changes through qcat_set_option /
+# qcat_clear_option.  The tests flip switches with monkeypatch.setenv("QCAT_HIP_<NAME>", value) / delenv -- written when the
+# library still called getenv() on every scan -- so MonkeyPatch forwards exactly those names to the option calls and puts the
+# previous values back in undo() (every MonkeyPatch object: the fixture's and the ones of monkeypatch.context()).
+def _forward_switches_to_the_option_abi():
+    from _pytest.monkeypatch import MonkeyPatch
+    if getattr(MonkeyPatch, "_qcat_forwarding", False):
+        return
+    orig_setenv, orig_delenv, orig_undo = MonkeyPatch.setenv, MonkeyPatch.delenv, MonkeyPatch.undo
+
+    def option_of(name):
+        if not name.startswith("QCAT_HIP_"):
+            return None
+        try:
+            from qcat_amd import native
+            lib = native.HipLibrary.get().lib
+        except Exception:
+            return None
+        return name[9:] if lib.qcat_get_option(name.encode(), None) >= 0 else None      # (QCAT_HIP_LIBRARY, _RCCL_LIB: not options)
+
+    def remember(self, opt):
+        from qcat_amd import native
+        saved = self.__dict__.setdefault("_qcat_saved_options", {})
+        if opt not in saved:
+            saved[opt] = native.get_option(opt)
+
+    def setenv(self, name, value, prepend=None):
+        orig_setenv(self, name, value, prepend)
+        opt = option_of(name)
+        if opt:
+            from qcat_amd import native
+            remember(self, opt)
+            native.set_option(opt, int(value) if str(value).strip() else 1)
+
+    def delenv(self, name, raising=True):
+        orig_delenv(self, name, raising)
+        opt = option_of(name)
+        if opt:
+            from qcat_amd import native
+            remember(self, opt)
+            native.set_option(opt, None)
+
+    def undo(self):
+        saved = self.__dict__.pop("_qcat_saved_options", {})
+        if saved:
+            from qcat_amd import native
+            for opt, value in saved.items():
+                native.set_option(opt, value)
+        orig_undo(self)
+
+    MonkeyPatch.setenv, MonkeyPatch.delenv, MonkeyPatch.undo = setenv, delenv, undo
+    MonkeyPatch._qcat_forwarding = True
+
+
+_forward_switches_to_the_option_abi()
+
+
+@pytest.fixture
+def hip_options():
+    """set library options for one test: hip_options(NO_GRAPH=1, BITSLICE_MIN=2048); None clears; restored afterwards"""
+    from qcat_amd import native
+    saved = {}
+
+    def set_(**kw):
+        for name, value in kw.items():
+            if name not in saved:
+                saved[name] = native.get_option(name)
+            native.set_option(name, value)
+    yield set_
+    for name, value in saved.items():
+        native.set_option(name, value)

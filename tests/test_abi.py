@@ -64,3 +64,47 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".inc", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle_lib" not in text and "libqcat_oracle" not in text and "qo_" not in text, f
+
+
+def test_switches_are_options_behind_the_abi_not_environment_reads(monkeypatch):
+    """Round 5: the library's tuning / diagnostic switches are one documented table (csrc/options.h).  QCAT_HIP_<NAME> is
+    read once at load; afterwards only qcat_set_option / qcat_clear_option change a switch -- a setenv() after the load
+    changes nothing (the tests' monkeypatch forwards to the option calls: tests/conftest.py)."""
+    hip = native.HipLibrary.get()
+    opts = native.options()
+    assert len(opts) == hip.lib.qcat_option_count() >= 50 and all(doc for _v, doc in opts.values())
+    assert native.get_option("NO_BITSLICE") is None
+    os.environ["QCAT_HIP_NO_BITSLICE"] = "1"                      # behind the library's back: not seen
+    try:
+        assert native.get_option("NO_BITSLICE") is None
+    finally:
+        del os.environ["QCAT_HIP_NO_BITSLICE"]
+    native.set_option("NO_BITSLICE", 1)
+    assert native.get_option("QCAT_HIP_NO_BITSLICE") == 1         # (either spelling)
+    native.set_option("NO_BITSLICE", None)
+    assert native.get_option("NO_BITSLICE") is None
+    monkeypatch.setenv("QCAT_HIP_BITSLICE_MIN", "2048")           # the forwarding the GPU tests rely on
+    assert native.get_option("BITSLICE_MIN") == 2048
+    monkeypatch.delenv("QCAT_HIP_BITSLICE_MIN")
+    assert native.get_option("BITSLICE_MIN") is None
+    with pytest.raises(RuntimeError, match="no option named"):
+        native.set_option("NO_SUCH_SWITCH", 1)
+    native.set_option("RAWS", 1)
+    native.reset_options()
+    assert native.get_option("RAWS") is None
+    # what is left of getenv() in the library: the RCCL path, the host thread count, the one import of the table
+    n = 0
+    for f in os.listdir(os.path.join(ROOT, "qcat_amd", "csrc")):
+        if f.endswith((".inc", ".hip", ".h")) and "generated" not in f:
+            n += len(re.findall(r"\bgetenv\(", open(os.path.join(ROOT, "qcat_amd", "csrc", f)).read()))
+    assert n <= 5, n
+
+
+def test_the_loader_refuses_another_implementation_of_the_abi():
+    """QCAT_HIP_LIBRARY names another BUILD of the library for A/B runs; the CPU oracle behind the same entry points
+    (oracle/libqcat_cpu.so, test infrastructure) must not load as the product."""
+    assert native.HipLibrary.get().lib.qcat_backend() == b"hip"
+    twin = os.path.join(ROOT, "oracle", "libqcat_cpu.so")
+    assert os.path.exists(twin)
+    with pytest.raises((RuntimeError, AttributeError)):
+        native.HipLibrary(path=twin)

@@ -197,11 +197,11 @@ def test_generic_device_path_matches_packed_path():
     kit = native.NativeKit(d)
     bases, offsets = native.pack_reads(reads)
     a = ctx().scan(kit, bases, offsets, trace=True, rows=True)
-    os.environ["QCAT_HIP_FORCE_GENERIC"] = "1"
+    native.set_option("FORCE_GENERIC", 1)                   # (read when a context is created)
     try:
         gctx = native.NativeContext(0)
     finally:
-        del os.environ["QCAT_HIP_FORCE_GENERIC"]
+        native.set_option("FORCE_GENERIC", None)
     b = gctx.scan(kit, bases, offsets, trace=True, rows=True)
     assert a[0].tobytes() == b[0].tobytes()
     for name in native.TRACE_DTYPE.names:

@@ -43,8 +43,8 @@ kit = det._native_kit(det.layouts, config.qcatConfig(), native.ENDS_BOTH)
 res = {"reads": n}
 sink = open(os.devnull, "wb")
 for workers, chunk in ((1, 1), (4, 1), (1, 16), (1, 64), (2, 64), (4, 64), (4, 256)):
-    os.environ["QCAT_HIP_AUTO_WORKERS"] = str(workers)
-    os.environ["QCAT_HIP_AUTO_CHUNK"] = str(chunk)
+    native.set_option("AUTO_WORKERS", workers)
+    native.set_option("AUTO_CHUNK", chunk)
     c = native.NativeContext(0)                               # a fresh context: the first call pays the helpers' set-up
     runs = []
     for rep in range(3):

@@ -126,10 +126,7 @@ for label, out, tsv in (("tsv", None, True), ("per_barcode_fastq", os.path.join(
 # ---- the driver's DEFAULT: kit auto, one vote per batch of 4000 reads (qcat/cli.py:500) -- every batch a call of its own;
 #      round 4: chunks of 64 batches per call (qcat_scan_batches_auto_ptrs: one vote per batch on the device), reads as pointers into the mapping
 for label, chunk in (("one_call_per_batch", "1"), ("default", None)):          # (round 3's loop; chunks of 64 batches per call)
-    if chunk:
-        os.environ["QCAT_HIP_AUTO_CHUNK"] = chunk
-    else:
-        os.environ.pop("QCAT_HIP_AUTO_CHUNK", None)
+    native.set_option("AUTO_CHUNK", int(chunk) if chunk else None)
     dt = min(run(big, "auto", None, True, True, tsv_file=os.path.join(tmp, "big_auto.tsv"))[0] for _ in range(2))
     res["native_tsv_kit_auto_" + label] = {"reads_per_s": round(n / dt, 1), "seconds": round(dt, 3)}
 res["note"] = ("host-bound: the file is split at parse_gb_per_s on the host threads, the scan reads heads and tails of the reads in "

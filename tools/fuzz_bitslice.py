@@ -18,7 +18,8 @@ import oracle_lib                    # noqa: E402
 import synth                         # noqa: E402
 from qcat_amd import config, native, scanner   # noqa: E402
 
-os.environ.setdefault("QCAT_HIP_BITSLICE_MIN", "2048")
+if native.get_option("BITSLICE_MIN") is None:
+    native.set_option("BITSLICE_MIN", 2048)
 first, last = int(sys.argv[1]), int(sys.argv[2])
 lib = native.HipLibrary.get().lib
 bad = ran_bs = 0

@@ -59,12 +59,9 @@ for seed in range(first, last):
     bases, offsets = native.pack_reads(reads)
     one_wave = rng.choice(["1", "0"])
     rows = rng.choice([None, None, str(rng.randrange(200, 6000))])
-    os.environ["QCAT_HIP_MIDDLE_ABS_MIN"] = "1"
-    os.environ["QCAT_HIP_MIDDLE_ABS_ONE_WAVE"] = one_wave
-    if rows:
-        os.environ["QCAT_HIP_MIDDLE_ABS_ROWS"] = rows
-    else:
-        os.environ.pop("QCAT_HIP_MIDDLE_ABS_ROWS", None)
+    native.set_option("MIDDLE_ABS_MIN", 1)
+    native.set_option("MIDDLE_ABS_ONE_WAVE", int(one_wave))
+    native.set_option("MIDDLE_ABS_ROWS", int(rows) if rows else None)
     cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
     got = ctx.scan(nk, bases, offsets, counts=cnt)
     tiles = (C.c_uint32 * 4)()
