@@ -317,19 +317,21 @@ def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
         want_tsv = fh.read()
     stream_best = None
     stream_ok = True
-    for reader in (1, 2, 1, 2):
-        with open(os.path.join(tmp, "stream.tsv"), "wb") as sink:
-            t1 = time.perf_counter()
-            bc, ad, none, ad_none, st2 = native.FastqFile.demux_stream(path, ctx, kit, det.layouts, mode == "dual", kit_auto=False, trim=True,
-                                                                        min_read_length=0, tsv_fd=sink.fileno(), reader=reader)
-            dt2 = time.perf_counter() - t1
-        with open(os.path.join(tmp, "stream.tsv"), "rb") as fh:
-            stream_ok = stream_ok and fh.read() == want_tsv
+    sink2 = open(os.path.join(tmp, "stream.tsv"), "w+b")
+    for reader in (0, 0, 0):                         # (the library's default reader: mapped windows)
+        sink2.seek(0)
+        t1 = time.perf_counter()
+        bc, ad, none, ad_none, st2 = native.FastqFile.demux_stream(path, ctx, kit, det.layouts, mode == "dual", kit_auto=False, trim=True,
+                                                                    min_read_length=0, tsv_fd=sink2.fileno(), reader=reader)
+        dt2 = time.perf_counter() - t1
+        sink2.seek(0)
+        stream_ok = stream_ok and sink2.read(len(want_tsv) + 1) == want_tsv
         called = (got["barcode_idx"] >= 0) & (got["adapter_idx"] >= 0) & ((got["barcode2_idx"] >= 0) | (mode != "dual"))
         stream_ok = stream_ok and int(bc.sum()) == int(called.sum()) and none == m - int(called.sum()) and int(ad.sum()) + ad_none == m \
             and st2["n_reads"] == m and not st2["incomplete"]
         if stream_best is None or dt2 < stream_best[0]:
             stream_best = (dt2, st2, reader)
+    sink2.close()
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))
     os.rmdir(tmp)
@@ -340,7 +342,7 @@ def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
     dt, st = best
     dt2, st2, reader = stream_best
     return {"value": round(m / dt2, 1), "unit": "reads/s", "reads": m, "file_gb": round(size / 1e9, 3),
-            "stream": {"reader": "pread" if reader == 1 else "mmap windows", "segments": st2["segments"],
+            "stream": {"reader": "mapped windows", "segments": st2["segments"],
                        "split_s": {k: round(st2[k], 4) for k in ("parse_s", "scan_s", "write_s", "total_s")}},
             "whole_file": {"value": round(m / dt, 1), "parse_gb_per_s": round(size / st["parse_s"] / 1e9, 2),
                            "split_s": {k: round(st[k], 4) for k in ("parse_s", "scan_s", "write_s", "total_s")}},

@@ -16,6 +16,7 @@ import synth                           # noqa: E402
 from qcat_amd import config, native, scanner   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+ballast = np.ones(int(float(os.environ.get("BALLAST_GB", "0")) * (1 << 30)), dtype=np.uint8) if os.environ.get("BALLAST_GB") else None   # (a resident array as big as bench.py's host batch)
 det = scanner.factory(kit="PBC096")
 block = synth.synth_batch(20000, 3, det.layouts, 1, 0, error_rate=0.08)
 tmp = tempfile.mkdtemp(prefix="qcat_bs_")
@@ -30,24 +31,41 @@ size = os.path.getsize(path)
 res = {"reads": n, "file_gb": round(size / 1e9, 3), "reader": [], "demux": []}
 
 
+import resource                        # noqa: E402
+
+
+def cpu_s():
+    u = resource.getrusage(resource.RUSAGE_SELF)
+    return u.ru_utime + u.ru_stime
+
+
+LAST_CPU = [0.0, 0.0]                  # user + system CPU seconds of the best run, of which system
+
+
 def best_of(f, k=3):
     b = None
     for _ in range(k):
+        u0 = resource.getrusage(resource.RUSAGE_SELF)
         t = time.perf_counter()
         r = f()
         dt = time.perf_counter() - t
+        u1 = resource.getrusage(resource.RUSAGE_SELF)
         if b is None or dt < b[0]:
             b = (dt, r)
+            LAST_CPU[0] = (u1.ru_utime - u0.ru_utime) + (u1.ru_stime - u0.ru_stime)
+            LAST_CPU[1] = u1.ru_stime - u0.ru_stime
     return b
 
 
 dt, _ = best_of(lambda: native.FastqFile(path).close())
 res["open_index_ms"] = round(dt * 1e3, 2)
+res["open_index_cpu_s"] = [round(LAST_CPU[0], 3), round(LAST_CPU[1], 3)]
 for reader in (1, 2):
-    for seg in (32 << 20, 64 << 20, 128 << 20, 256 << 20):
+    for seg in (64 << 20, 256 << 20):
         dt, r = best_of(lambda: native.FastqFile.stream_count(path, seg, 4000, reader))
         assert r[0] == n
-        res["reader"].append({"reader": reader, "segment_mb": seg >> 20, "ms": round(dt * 1e3, 2), "gb_per_s": round(size / dt / 1e9, 1)})
+        res["reader"].append({"reader": reader, "segment_mb": seg >> 20, "ms": round(dt * 1e3, 2), "gb_per_s": round(size / dt / 1e9, 1),
+                              "cpu_s": [round(LAST_CPU[0], 3), round(LAST_CPU[1], 3)]})
 cfg = config.qcatConfig()
 kit = det._native_kit(det.layouts, cfg, native.ENDS_BOTH)
 ctx = det._context()
@@ -59,14 +77,15 @@ with open(os.path.join(tmp, "a.tsv"), "wb") as sink:
         f.close()
         return out
     dt, st = best_of(whole)
-    res["whole_file"] = {"ms": round(dt * 1e3, 2), "m_reads_per_s": round(n / dt / 1e6, 2), "split_s": {k: round(v, 4) for k, v in st.items() if k.endswith("_s")}}
-    for reader in (1, 2):
-        for seg in (64 << 20, 128 << 20, 256 << 20):
+    res["whole_file"] = {"ms": round(dt * 1e3, 2), "m_reads_per_s": round(n / dt / 1e6, 2), "cpu_s": [round(LAST_CPU[0], 3), round(LAST_CPU[1], 3)], "split_s": {k: round(v, 4) for k, v in st.items() if k.endswith("_s")}}
+    for reader in (2,):
+        for seg in (128 << 20, 256 << 20, 512 << 20):
             def stream():
                 sink.seek(0)
                 return native.FastqFile.demux_stream(path, ctx, kit, det.layouts, False, trim=True, tsv_fd=sink.fileno(), segment_bytes=seg, reader=reader)[4]
             dt, st = best_of(stream)
             res["demux"].append({"reader": reader, "segment_mb": seg >> 20, "ms": round(dt * 1e3, 2), "m_reads_per_s": round(n / dt / 1e6, 2),
+                                 "cpu_s": [round(LAST_CPU[0], 3), round(LAST_CPU[1], 3)],
                                  "split_s": {k: round(v, 4) for k, v in st.items() if k.endswith("_s")}})
 os.remove(path)
 for f in os.listdir(tmp):
