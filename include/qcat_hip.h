@@ -382,6 +382,13 @@ void* qcat_ctx_stream(qcat_ctx* ctx);
  * and tests; -1: null context. */
 int64_t qcat_ctx_graph_replays(const qcat_ctx* ctx);
 
+/* Diagnostics of the context's latest scan of the read ends (find_highest_scoring_barcode, qcat/scanner_base.py:63-141, on the
+ * bit-sliced kernels of csrc/kernels_bitslice.inc): super-tiles of 2048 barcode alignments taken per hot class, summed over the
+ * (template, set) groups -- out[0] = regions 1..5 bases short of the nominal length (clipped by the window: units padded at the
+ * front, ABI 5), out[1] = nominal regions, out[2] = full windows; all zero when the batch was too small for the path.
+ * Synchronises the context's stream.  Tests and diagnostics. */
+int qcat_ctx_barcode_bitslice_tiles(qcat_ctx* ctx, uint32_t out[3]);
+
 /* Diagnostics of the context's latest --detect-middle scan (detect_barcode's interior scan, qcat/scanner_base.py:479-519,
  * :593-595): out[0] = tiles of 2048 interiors whose adapter scan ran in bit-sliced form (csrc/kernels_abs_mid.inc), out[1] =
  * such tiles in all, out[2] = tiles of 128 interiors left to the binary16 kernel (a letter outside A, C, G, T, a kit without

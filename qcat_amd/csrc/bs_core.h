@@ -132,6 +132,15 @@ BS_FN void bs_cell(u32 neq, u32& a1, u32& a0, u32& b1, u32& b0) {
     a1 = p1; a0 = p0; b1 = q1; b0 = q0;
 }
 
+// Front padding (round 5: regions a few bases shorter than the nominal length share the nominal units).  An alignment whose
+// region has p rows fewer than the unit starts p rows late: semi-global alignment starts from H(0, j) = 0 whatever came
+// before, so until its first row it is simply HELD at the boundary state -- after each of the unit's first rows the dh
+// planes of the alignments that have not started (mask hm) go back to 1 (bs_hold), the trailing columns' reversed DP, which
+// meets those rows LAST, keeps the state it had after the alignment's own last row and hands out r = 0 for them
+// (bs_keep; with r = 0 the deficit stays 0: D' = max(0 + 0 - a, 0)), and every alignment ends in the unit's last row.
+BS_FN void bs_hold(u32& h1, u32& h0, u32 hm) { h1 &= ~hm; h0 |= hm; }
+BS_FN void bs_keep(u32& h, u32 old, u32 hm) { h = bs_bfi(hm, old, h); }
+
 // letter mismatch mask: planes (c1 c0) of the alignments' letters against the wave-uniform letter (L1 L0), each 0 / ~0
 BS_FN u32 bs_neq(u32 c1, u32 c0, u32 L1, u32 L0) {
     return QB3(c1 ^ L1, c0, L0, x | (y ^ z));

@@ -27,6 +27,8 @@ constexpr int MAX_TARGET = QCAT_MAX_TARGET_LEN;
 constexpr int MAX_WIN = QCAT_MAX_WINDOW;
 constexpr int WIN_STRIDE = 160;          // bytes per packed code window (16-B aligned rows)
 constexpr int WIN2_WORDS = WIN_STRIDE / 16; // dwords of a window at two bits per code (k_pack_windows: win2)
+constexpr int BS_PAD_ROWS = 5;              // rows a region of the "short of nominal" class may miss (front padding of the bit-sliced barcode units)
+constexpr int WIN2_FRONT = 16;              // dwords of slack in front of the first window of the context's win2 buffer
 constexpr int RAW_NEVER = 1 << 20;       // "no raw score passes"
 constexpr int PADMAX = 8;                // most leading padding columns a width class may have
 
@@ -63,6 +65,7 @@ struct DevSet {
     int32_t bs_rev;             // ... rows and target letters run backwards (the downstream context is the longer one)
     int32_t bs_post;            // ... trailing columns (11 / 8 / 7 / 6 / 4 / 0 letters of the other context) that every barcode shares as well:
                                 // computed once per super-tile by the reversed DP (bs_core.h, round 5); own columns = tlen - bs_pre - bs_post
+    int32_t bs_short_min;       // ... regions of bs_short_min .. hot_len - 1 rows share the nominal units, padded at the front (round 5; hot_len: no such class)
     int32_t bs_kernel;          // bit-sliced kernel with this set's letters compiled in (static_generated.inc / run-time code), -1: none
     int32_t bs_case_off;        // ids blob: per barcode its case of that kernel
     int32_t len_off;            // simple mode, barcodes of unequal length: ids blob, per barcode (length, min_raw_pass, min_raw_conflict);

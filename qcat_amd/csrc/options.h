@@ -28,6 +28,7 @@
     X(BITSLICE_PAD, "jobs from which the rest of a hot class becomes a padded super-tile (0 / unset: never)") \
     X(BS_FROM_TILES, "1: bit-sliced units read tile images instead of the two-bit windows") \
     X(BS_NO_SOLO, "1: no producer waves for the shared columns") \
+    X(BS_NO_SHORT, "1: regions a few bases short of nominal stay on the binary16 kernels (no front-padded units)") \
     X(BS_NO_TAIL_SPLIT, "1: the last round of long units is not cut into barcode chunks") \
     X(BS_SERIAL, "1: the bit-sliced launches of a scan in line on the context's stream") \
     X(BS_SIDE, "1: ... on side streams whatever the batch size") \

@@ -853,7 +853,9 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     if ((rc = grow(&c->win, &c->cap_win, n_ends * WIN_STRIDE + 512))) return rc;    // + slack: k_job_gather reads whole dwords, k_bs_barcode 84 bytes from any region start
     if ((rc = grow(&c->wlen, &c->cap_wlen, n_ends))) return rc;
     if ((rc = grow(&c->wspec, &c->cap_wspec, n_ends))) return rc;
-    if ((rc = grow(&c->win2, &c->cap_win2, n_ends * WIN2_WORDS + 64))) return rc;      // + slack: readers take whole dwords past a region's end
+    // + slack: readers take whole dwords past a region's end -- and, round 5, one dword in FRONT of the first window (a front-padded
+    // unit of the bit-sliced barcode kernels fetches from up to BS_PAD_ROWS bases before a region): the windows start WIN2_FRONT words in
+    if ((rc = grow(&c->win2, &c->cap_win2, n_ends * WIN2_WORDS + 64 + WIN2_FRONT))) return rc;
     if ((rc = grow(&c->recs, &c->cap_recs, n_ends))) return rc;
     if ((rc = grow(&c->results, &c->cap_reads, (size_t)n))) return rc;
     if ((rc = grow(&c->counts, &c->cap_buckets, (size_t)hk.n_buckets))) return rc;
@@ -922,7 +924,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
             for (int t = 0; t < hk.nt && lazy; ++t) lazy = hk.tpl[t].static_kernel >= 0;
             c->packed.lazy = lazy;
             hipLaunchKernelGGL(k_pack_windows, dim3(blocks), dim3(256), 0, c->stream,
-                               b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen, c->wspec, c->win2, lazy ? 1 : 0);
+                               b->bases, b->offsets, n, ends, hk.max_align, c->win, c->wlen, c->wspec, c->win2 + WIN2_FRONT, lazy ? 1 : 0);
             if (lazy) hipLaunchKernelGGL(k_expand_special, dim3((uint32_t)((n_ends + 255) / 256)), dim3(256), 0, c->stream,
                                          b->bases, b->offsets, n, ends, hk.max_align, c->wspec, c->win);
         }
@@ -938,7 +940,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     if (hk.mode == QCAT_MODE_SIMPLE && adapter_only) return set_err(QCAT_ERR_ARG, "simple mode has no adapter templates to vote with");
     if (resume_kit_mask >= 0 && !(use_packed && c->packed.slices_single))
         return set_err(QCAT_ERR_UNSUPPORTED, "the adapter pass of this kit cannot be resumed per kit (table or general kernels)");
-    c->packed.wspec = c->wspec; c->packed.win = c->win; c->packed.win2 = c->win2_valid ? c->win2 : nullptr;
+    c->packed.wspec = c->wspec; c->packed.win = c->win; c->packed.win2 = c->win2_valid ? c->win2 + WIN2_FRONT : nullptr;
     // packed barcode results (kernels_bitslice.inc: k_bs_select_ordered) instead of 8 bytes scattered into every record;
     // debug scans keep the records complete for the traces
     const bool slim = use_packed && !debug && hk.mode != QCAT_MODE_SIMPLE && !opt_on(QO_NO_SLIM);
@@ -1020,6 +1022,23 @@ extern "C" int qcat_ctx_fetch_counts(qcat_ctx* c, int64_t* counts, int32_t n_buc
 
 extern "C" void* qcat_ctx_stream(qcat_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int64_t qcat_ctx_graph_replays(const qcat_ctx* c) { return c ? (int64_t)(c->api_graph.replays + c->scan_graph.replays) : -1; }
+// diagnostics of the latest scan of the read ends: super-tiles (2048 barcode alignments each) its bit-sliced barcode kernels took, per
+// hot class summed over the (template, set) groups -- out[0] regions a few bases short of nominal (front-padded units), out[1]
+// nominal regions, out[2] full windows; all 0 when the path was not taken
+extern "C" int qcat_ctx_barcode_bitslice_tiles(qcat_ctx* c, uint32_t* out) {
+    if (!c || !out) return set_err(QCAT_ERR_ARG, "null argument");
+    out[0] = out[1] = out[2] = 0;
+    if (!c->packed.bsplan || !c->packed.bs_last) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    BsPlan hp;
+    HIPCHK(hipMemcpy(&hp, c->packed.bsplan, sizeof hp, hipMemcpyDeviceToHost));
+    for (int b = 0; b < JOB_BINS; ++b) {
+        const int cls = b % JOB_CLASSES - (JOB_CLASSES - JOB_HOT);
+        if (cls >= 0) out[cls] += hp.count[b];
+    }
+    return 0;
+}
 // diagnostics of the latest --detect-middle scan: out[0] = big tiles (2048 interiors) its bit-sliced adapter scan walked, out[1] = big
 // tiles in all, out[2] = tiles of 128 interiors left to the binary16 kernel, out[3] = tiles of 128 in all (all 0: path not taken)
 extern "C" int qcat_ctx_middle_bitslice_tiles(qcat_ctx* c, uint32_t* out) {

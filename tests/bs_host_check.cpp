@@ -76,11 +76,25 @@ struct P2 { u32 p1, p0; };
 
 // one unit: 32 regions of L rows against every target of a family.  split: the round-5 form (P shared leading columns, Q
 // trailing columns through the reversed DP, C own); otherwise the unsplit form (P shared, C + Q own)
-static int check_unit(const std::vector<std::string>& targets, bool rev, int P, int Q, int L, bool split, const int8_t* mat) {
+// maxpad > 0 (split form only): alignment k's region is pad[k] <= maxpad rows shorter than the unit and starts pad[k] rows late
+// (front padding, bs_hold / bs_keep); the rows in front of it hold arbitrary letters
+static int check_unit(const std::vector<std::string>& targets, bool rev, int P, int Q, int L, bool split, const int8_t* mat, int maxpad = 0) {
     const int M = (int)targets[0].size();
     const int C = split ? M - P - Q : M - P;
-    std::vector<std::string> reg(32);
-    for (auto& r : reg) r = make_region(targets, L);
+    std::vector<std::string> reg(32), real(32);
+    int pad[32];
+    for (int k = 0; k < 32; ++k) {
+        pad[k] = maxpad ? below(std::min(maxpad, L - 1) + 1) : 0;
+        real[(size_t)k] = make_region(targets, L - pad[k]);
+        // the unit's rows in region order: forward sets are padded in front of the region, reversed sets behind it (their rows
+        // run backwards, so that is the front of the walk as well)
+        std::string junk;
+        for (int i = 0; i < pad[k]; ++i) junk.push_back(BASES[below(4)]);
+        reg[(size_t)k] = rev ? real[(size_t)k] + junk : junk + real[(size_t)k];
+    }
+    std::vector<u32> hold((size_t)std::max(1, maxpad), 0u);          // hold[i]: alignments that have not started in walk row i
+    for (int i = 0; i < maxpad; ++i)
+        for (int k = 0; k < 32; ++k) if (pad[k] > i) hold[(size_t)i] |= 1u << k;
     std::vector<P2> row((size_t)L), dvp((size_t)L), dvr((size_t)L);
     for (int i = 0; i < L; ++i) {                    // letter planes in the order the rows are walked
         u32 c1 = 0, c0 = 0;
@@ -99,6 +113,7 @@ static int check_unit(const std::vector<std::string>& targets, bool rev, int P, 
         for (int i = 0; i < L; ++i) {
             u32 a1 = 0u, a0 = 0xFFFFFFFFu;
             for (int j = 0; j < P; ++j) bs_cell(bs_neq_letter(code_of(w0[(size_t)j]), row[(size_t)i].p1, row[(size_t)i].p0), a1, a0, h1[(size_t)j], h0[(size_t)j]);
+            if (i < maxpad) for (int j = 0; j < P; ++j) bs_hold(h1[(size_t)j], h0[(size_t)j], hold[(size_t)i]);
             dvp[(size_t)i] = P2{a1, a0};
         }
         for (int q = 0; q < BS_NB; ++q) { tail_r[q] = (BS_OFF >> q) & 1 ? 0xFFFFFFFFu : 0u; tail_best[q] = 0u; }
@@ -111,10 +126,25 @@ static int check_unit(const std::vector<std::string>& targets, bool rev, int P, 
         std::vector<u32> h1((size_t)Q, 0u), h0((size_t)Q, 0xFFFFFFFFu);
         for (int i = L - 1; i >= 0; --i) {
             u32 a1 = 0u, a0 = 0xFFFFFFFFu;
+            const std::vector<u32> o1 = h1, o0 = h0;
             for (int j = 0; j < Q; ++j) bs_cell(bs_neq_letter(code_of(w0[(size_t)(M - 1 - j)]), row[(size_t)i].p1, row[(size_t)i].p0), a1, a0, h1[(size_t)j], h0[(size_t)j]);
+            if (i < maxpad) {                          // rows in front of an alignment's first one: its state stays, r = 0
+                const u32 hm = hold[(size_t)i];
+                for (int j = 0; j < Q; ++j) { bs_keep(h1[(size_t)j], o1[(size_t)j], hm); bs_keep(h0[(size_t)j], o0[(size_t)j], hm); }
+                a1 &= ~hm; a0 &= ~hm;
+            }
             dvr[(size_t)i] = P2{a1, a0};
         }
-        if (Q == 0) dvr[0] = P2{0u, 0u};              // no trailing column: G(0) = H(0, M) is no cell -- the first step cannot keep it
+        // no trailing column: G(first row - 1) = H(0, M) is no cell -- the first step of an alignment cannot keep it (r = 0 in ITS
+        // first row: the row behind its padding)
+        if (Q == 0) {
+            if (!maxpad) dvr[0] = P2{0u, 0u};
+            else for (int i = 0; i < L; ++i) {
+                u32 first = 0;
+                for (int k = 0; k < 32; ++k) if (pad[k] == i) first |= 1u << k;
+                dvr[(size_t)i].p0 &= ~first;
+            }
+        }
         u32 r[BS_NB];
         for (int q = 0; q < BS_NB; ++q) r[q] = (BS_OFF >> q) & 1 ? 0xFFFFFFFFu : 0u;
         for (int j = 0; j < Q; ++j) { bs_step(r, h1[(size_t)j], h0[(size_t)j]); bs_max(cmax, r); }
@@ -129,6 +159,7 @@ static int check_unit(const std::vector<std::string>& targets, bool rev, int P, 
         for (int i = 0; i < L; ++i) {
             u32 a1 = P ? dvp[(size_t)i].p1 : 0u, a0 = P ? dvp[(size_t)i].p0 : 0xFFFFFFFFu;
             for (int j = 0; j < C; ++j) bs_cell(bs_neq_letter(code_of(w[(size_t)(P + j)]), row[(size_t)i].p1, row[(size_t)i].p0), a1, a0, h1[(size_t)j], h0[(size_t)j]);
+            if (i < maxpad) for (int j = 0; j < C; ++j) bs_hold(h1[(size_t)j], h0[(size_t)j], hold[(size_t)i]);
             if (split) bs_deficit_split(d, a1, a0, dvr[(size_t)i].p1, dvr[(size_t)i].p0);
             else bs_deficit(f, a1, a0);
         }
@@ -142,10 +173,10 @@ static int check_unit(const std::vector<std::string>& targets, bool rev, int P, 
             for (int q = 0; q < BS_NB; ++q) got |= (int)((best[q] >> k) & 1u) << q;
             got -= BS_OFF;
             int32_t ws = 0, wq = 0, wr = 0;
-            qo_sg(reg[(size_t)k].c_str(), L, tgt.c_str(), M, 1, 1, mat, &ws, &wq, &wr);
+            qo_sg(real[(size_t)k].c_str(), L - pad[k], tgt.c_str(), M, 1, 1, mat, &ws, &wq, &wr);
             if (got != ws) {
-                if (bad < 5) fprintf(stderr, "MISMATCH %s rev %d P %d Q %d L %d region %s target %s: got %d want %d\n",
-                                     split ? "split" : "unsplit", (int)rev, P, Q, L, reg[(size_t)k].c_str(), tgt.c_str(), got, ws);
+                if (bad < 5) fprintf(stderr, "MISMATCH %s rev %d P %d Q %d L %d pad %d region %s target %s: got %d want %d\n",
+                                     split ? "split" : "unsplit", (int)rev, P, Q, L, pad[k], real[(size_t)k].c_str(), tgt.c_str(), got, ws);
                 ++bad;
             }
         }
@@ -176,17 +207,18 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 16; ++i) pick.push_back(targets[(size_t)below((int)targets.size())]);
             targets.swap(pick);
         }
-        int bad_split = 0, bad_plain = 0;
+        int bad_split = 0, bad_plain = 0, bad_padded = 0;
         long n = 0;
         for (int r = 0; r < rounds; ++r)
             for (int L : LENS) {
                 bad_split += check_unit(targets, rev != 0, P, Q, L, true, mat);
                 bad_plain += check_unit(targets, rev != 0, P, 0, L, false, mat);
+                if (L > 1) bad_padded += check_unit(targets, rev != 0, P, Q, L, true, mat, 5);
                 n += 32 * (long)targets.size();
             }
-        printf("family %d (%s, %d shared + %d own + %d trailing columns): %ld alignments each way, split: %d mismatches, unsplit: %d mismatches\n",
-               fam, rev ? "reversed" : "forward", P, (int)targets[0].size() - P - Q, Q, n, bad_split, bad_plain);
-        total += bad_split + bad_plain;
+        printf("family %d (%s, %d shared + %d own + %d trailing columns): %ld alignments each way, split: %d mismatches, unsplit: %d mismatches, front-padded: %d mismatches\n",
+               fam, rev ? "reversed" : "forward", P, (int)targets[0].size() - P - Q, Q, n, bad_split, bad_plain, bad_padded);
+        total += bad_split + bad_plain + bad_padded;
         ++fam;
     }
     return total ? 1 : 0;

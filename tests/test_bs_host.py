@@ -68,4 +68,4 @@ def test_bit_sliced_barcode_arithmetic_equals_the_oracle_dp(host_check, tmp_path
     out = p.stdout.decode()
     assert p.returncode == 0, out[-3000:] + p.stderr.decode()[-3000:]
     rows = [l for l in out.splitlines() if l.startswith("family")]
-    assert len(rows) == len(lines) and all(l.endswith("split: 0 mismatches, unsplit: 0 mismatches") for l in rows), out[-3000:]
+    assert len(rows) == len(lines) and all(l.endswith("split: 0 mismatches, unsplit: 0 mismatches, front-padded: 0 mismatches") for l in rows), out[-3000:]

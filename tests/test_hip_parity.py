@@ -652,3 +652,46 @@ def test_bit_sliced_adapter_kernels_equal_the_binary16_kernels_and_the_oracle(mo
         bad = np.nonzero(recs != o_recs)[0]
         assert len(bad) == 0, (variant, bad[:10], recs[bad[:3]], o_recs[bad[:3]])
         assert np.array_equal(cnt, o_cnt)
+
+
+@pytest.mark.parametrize("mode,kit,t5,t3,custom", [("epi2me", "PBC096", 1, 0, False), ("epi2me", "NBD103/NBD104", 1, 0, False),
+                                                   ("dual", None, 1, 0, False), ("epi2me", "NBD104/NBD114", 1, 0, False),
+                                                   ("epi2me", "PBC096", 1, 0, True)])
+def test_bit_sliced_units_padded_at_the_front_for_regions_short_of_nominal(mode, kit, t5, t3, custom, monkeypatch):
+    """Round 5: a barcode region clipped by its window -- 1 .. 5 bases short of the nominal length (0.64 % of config 3's jobs, 2 %
+    of its step on the binary16 kernels) -- shares the nominal units' row count: its alignment starts a few rows late and is
+    held at the boundary state until then (csrc/bs_core.h: bs_hold / bs_keep).  Reads whose adapter starts within a few bases of
+    the read's end, so that the region in front of the barcode runs out of the window (both ends; the first bases of some reads
+    cut away as well), small batches with the path forced and the class's rest taken as a padded super-tile; static letters, letters from memory, the class off; records
+    and counts against the oracle, and the diagnostics say that front-padded units did run."""
+    cfg = config.qcatConfig()
+    if custom:                                            # another geometry: generated kernels through hipRTC
+        cfg.barcode_context_length = 9
+        cfg.extracted_barcode_extension = 8
+    det = scanner.factory(mode=mode, kit=kit)
+    n = 9000
+    reads = synth.synth_batch(n, 515, det.layouts, t5, t3, error_rate=0.06, lead_min=0, lead_max=8)
+    for i in range(0, n, 7):
+        reads[i] = reads[i][(i % 5):len(reads[i]) - (i % 9)]     # windows that start / end inside the adapter's first bases
+    reads[3], reads[4] = "", "ACGT" * 30
+    d = det.descriptor(qcat_config=cfg)
+    want, want_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
+    bases, offsets = native.pack_reads(reads)
+    monkeypatch.setenv("QCAT_HIP_BITSLICE_MIN", "2048")
+    monkeypatch.setenv("QCAT_HIP_BITSLICE_PAD", "128")
+    lib = native.HipLibrary.get().lib
+    for variant in ("static letters", "letters from memory", "short class off"):
+        if variant == "letters from memory":
+            monkeypatch.setenv("QCAT_HIP_NO_BS_STATIC", "1")
+        elif variant == "short class off":
+            monkeypatch.delenv("QCAT_HIP_NO_BS_STATIC")
+            monkeypatch.setenv("QCAT_HIP_BS_NO_SHORT", "1")
+        cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+        ctx = native.NativeContext(0)
+        got = ctx.scan(native.NativeKit(d, jit=True), bases, offsets, counts=cnt)
+        tiles = (C.c_uint32 * 3)()
+        native.HipLibrary.get().check(lib.qcat_ctx_barcode_bitslice_tiles(ctx.handle, tiles))
+        assert (tiles[0] > 0) == (variant != "short class off") and tiles[1] + tiles[2] > 0, (variant, list(tiles))
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, (variant, bad[:10], got[bad[:3]], want[bad[:3]])
+        assert np.array_equal(cnt, want_cnt)
