@@ -162,7 +162,13 @@ def main():
     ctx = native.NativeContext(local_rank)
     n_buckets = desc.n_count_buckets
     use_comm = world > 1 or "RANK" in os.environ           # launcher environment (also with one process)
-    comm = parallel.init_comm(ctx, rank, world) if use_comm else None
+    t_comm = time.perf_counter()
+
+    def comm_stage(name):
+        # start-up of N > 1 ranks dies in one of three places that look alike from outside: say where this rank is
+        sys.stderr.write("[bench.py rank %d/%d +%.2f s] %s\n" % (rank, world, time.perf_counter() - t_comm, name))
+        sys.stderr.flush()
+    comm = parallel.init_comm(ctx, rank, world, trace=comm_stage if world > 1 else None) if use_comm else None
 
     sp = native.SynthParams(seed=a.seed + 1000003 * rank, n_reads=a.reads, insert_len=600, lead_min=5,
                             lead_max=40, error_rate=a.error_rate, no_adapter_fraction=0.05,

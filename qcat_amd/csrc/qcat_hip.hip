@@ -698,11 +698,16 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
         c->cap_mid_slots = slots;
     }
     if ((rc = grow(&c->mid_bests, &c->cap_mid_bests, slots * (size_t)hk.nt))) return rc;
-    HIPCHK(hipMemsetAsync(c->mid_tables, 0, sizeof(MidTables), st));
-    HIPCHK(hipMemsetAsync(c->mid_slot, 0xFF, (size_t)n * 4, st));
-    HIPCHK(hipMemsetAsync(c->mid_sorted, 0xFF, slots * 4, st));
-    HIPCHK(hipMemsetAsync(c->mid_len, 0, slots * 4, st));
-    HIPCHK(hipMemsetAsync(c->mid_fallback, 0, slots * 4, st));
+    // the fills of the interior scan leave as two k_fill_multi launches (round 5; thirteen memsets of 5-7 us each before):
+    // the slot tables here, the job tables / sorted list / redo count / letter flags / tile cursors before the adapter phase
+    const bool merge_fills = !opt_on(QO_NO_FILL_MERGE);
+    g_fill.n = 0; g_fill_defer = merge_fills;
+    HIPCHK(packed_fill(c->mid_tables, 0, sizeof(MidTables), st));
+    HIPCHK(packed_fill(c->mid_slot, 0xFF, (size_t)n * 4, st));
+    HIPCHK(packed_fill(c->mid_sorted, 0xFF, slots * 4, st));
+    HIPCHK(packed_fill(c->mid_len, 0, slots * 4, st));
+    HIPCHK(packed_fill(c->mid_fallback, 0, slots * 4, st));
+    HIPCHK(packed_fill_flush(st));
     const uint32_t rblocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + 255) / 256, 2048);
     hipLaunchKernelGGL(k_mid_count, dim3(rblocks), dim3(256), 0, st, kp.kit, b->offsets, n, c->results, c->mid_tables, c->mid_generic);
     hipLaunchKernelGGL(k_mid_offsets, dim3(1), dim3(1024), 0, st, c->mid_tables);
@@ -727,6 +732,8 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     sc->win = c->win;                                     // (never read: the job regions come from win2, `lazy`)
     sc->lazy = mid_bs;
     sc->slim = false;                                     // ... and the barcode results stay in the interior's own records
+    g_fill.n = 0; g_fill_defer = merge_fills;                  // (flushed in front of the adapter phase below; every return before drops the list)
+    struct FillGuard { ~FillGuard() { g_fill_defer = false; g_fill.n = 0; } } fill_guard;
     if ((rc = packed_prepare(st, hk, (uint32_t)slots, sc))) return set_err(rc, packed_last_error());
     const uint32_t tiles = (uint32_t)(slots / PK_TILE);
     // round 4: the adapter scan of the interiors in bit-sliced form (kernels_abs_mid.inc) from QCAT_HIP_MIDDLE_ABS_MIN slots
@@ -772,14 +779,15 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             am.cursor = w + (size_t)big * (4 + 128);
             am.c2 = c->absm_c2 + C2_SLACK; am.rspec = c->absm_rspec; am.sinfo = c->absm_sinfo; am.n_bases = b->n_bases; am.n_reads = n;
             if (early) HIPCHK(hipStreamWaitEvent(st, c->absm_done, 0));
-            else HIPCHK(hipMemsetAsync(c->absm_rspec, 0, (size_t)n + 1, st));
+            else HIPCHK(packed_fill(c->absm_rspec, 0, (size_t)n + 1, st));
             am.need128 = c->absm_need; am.planes = c->absm_planes; am.ns = c->absm_ns; am.row_cap = (uint32_t)rows;
             am.bests = c->mid_bests; am.tpl = -1; am.den = 0; am.kit_slot = -1;
             // issue priority of the row loops rotated every two rows by workgroup parity (abs_setprio; two waves of different
             // launches share a SIMD): 4.79 against 4.91 ms per step at 1 M reads (tools/r04_absmid_prio.sh); QCAT_HIP_MIDDLE_ABS_PRIO
             const QOptVal pr = opt_is_set(QO_MIDDLE_ABS_PRIO) ? qopt_get(QO_MIDDLE_ABS_PRIO) : qopt_get(QO_ABS_PRIO);
             am.prio = pr ? atoi(pr) : 2;
-            HIPCHK(hipMemsetAsync(am.cursor, 0, MAX_T * 4, st));
+            HIPCHK(packed_fill(am.cursor, 0, MAX_T * 4, st));
+            HIPCHK(packed_fill_flush(st));
             // the M-ends' first windows (k_mid_windows) come from the packed batch too: QCAT_HIP_MIDDLE_ABS_WINDOWS=0: from the reads, beside
             const bool c2win = mid_bs && !((opt_is_set(QO_MIDDLE_ABS_WINDOWS) && opt_val(QO_MIDDLE_ABS_WINDOWS, 0) == 0));
             fork_join(sc, st, (mid_bs && !c2win) ? 2 : 1, [&](int i, hipStream_t q) {
@@ -789,6 +797,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             c->absm_last_big = big; c->absm_last_128 = tiles;
         }
     }
+    HIPCHK(packed_fill_flush(st));                                 // (no bit-sliced interior scan: the job tables' fills leave here)
     int absm_side = 0;                                             // templates on the bit-sliced path: launches side by side
     if (use_absm) for (int t = 0; t < hk.nt; ++t) if ((am.kit_mask >> hk.tpl[t].kit_slot) & 1u) ++absm_side;
     if (mid_bs && !use_absm) launch_mid_windows(st);

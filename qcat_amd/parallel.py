@@ -154,23 +154,47 @@ def exchange_id(rank, world_size, make_id, environ=None, timeout=300.0):
     raise RuntimeError("rendezvous: rank {} could not reach rank 0 at {}:{}".format(rank, addr, ports))
 
 
-def init_comm(ctx, rank=None, world_size=None, environ=None):
+COMM_STAGES = ("rendezvous", "ncclCommInitRank", "first all-reduce", "ready")
+
+
+def init_comm(ctx, rank=None, world_size=None, environ=None, trace=None):
     """The RCCL communicator of this rank: rank 0 creates the unique id in the native library, the
-    id travels by :func:`exchange_id`, every rank joins (collective)."""
+    id travels by :func:`exchange_id`, every rank joins (collective), and one all-reduce of a 1 per rank
+    proves the ring before any timed work.  ``trace(stage)`` is called on entering each of
+    :data:`COMM_STAGES`; a failure is re-raised naming the rank and the stage it was in -- the three
+    places a multi-GPU start-up dies in look alike from outside (a hang or a bare RCCL error code)."""
     r, _lr, w = rank_env(environ)
     rank = r if rank is None else rank
     world_size = w if world_size is None else world_size
-    uid = exchange_id(rank, world_size, native.comm_unique_id, environ)
-    # RCCL writes a version banner to the C stdout of rank 0 while the communicator is built; callers
-    # that print machine-readable results on stdout get it on stderr instead
-    sys.stdout.flush()
-    saved = os.dup(1)
+    stage = [COMM_STAGES[0]]
+
+    def enter(name):
+        stage[0] = name
+        if trace is not None:
+            trace(name)
+
     try:
-        os.dup2(2, 1)
-        return native.NativeComm(ctx, world_size, rank, uid)
-    finally:
-        os.dup2(saved, 1)
-        os.close(saved)
+        enter("rendezvous")
+        uid = exchange_id(rank, world_size, native.comm_unique_id, environ)
+        # RCCL writes a version banner to the C stdout of rank 0 while the communicator is built; callers
+        # that print machine-readable results on stdout get it on stderr instead
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            enter("ncclCommInitRank")
+            comm = native.NativeComm(ctx, world_size, rank, uid)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        enter("first all-reduce")
+        got = comm.allreduce([1.0], native.REDUCE_SUM)[0]
+        if int(round(got)) != world_size:
+            raise RuntimeError("all-reduce of one per rank gave {} for {} ranks".format(got, world_size))
+        enter("ready")
+        return comm
+    except Exception as e:
+        raise RuntimeError("rank {} of {} failed in stage '{}': {}".format(rank, world_size, stage[0], e)) from e
 
 
 def _cgroup_cpu_quota():

@@ -154,3 +154,56 @@ def sg_stats(s1, s2, gap_open, gap_extend, score, alphabet="ATGCNX", rule="paras
     matches, length = MH[end_ref + 1][end_query + 1]
     assert H[end_ref + 1][end_query + 1] == best
     return best, end_query, end_ref, matches, length
+
+
+def sg_unique_path(s1, s2, gap_open, gap_extend, score):
+    """-> (n_optimal, (score, end_query, end_ref, matches, length)): the number of DISTINCT optimal alignments (capped at 2)
+    and -- meaningful when that number is 1 -- the statistics of the only one.
+
+    An alignment is a sequence of columns (diagonal / gap in the target / gap in the query) from a cell of the first row or
+    first column to a cell of the last row or last column.  Counted over three states per cell (ends in a diagonal step D, in
+    a gap that consumes a target letter E, in a gap that consumes a query letter F) with E -> E and F -> F as the ONLY
+    extension moves, so that every column sequence is one state path and is counted once (the H-based recurrence of sg()
+    reaches "open from an H that came from E" as a second derivation of the same columns when open == extend).
+    When the count is 1 there is no tie anywhere -- not among the border cells that end the alignment, not along the path --
+    and (matches, length) are facts of the inputs: every correct implementation has to report them, whatever its tie order.
+    A match here = the same letter; callers keep to A, C, G, T, where every rule of sg_stats agrees on what a match is."""
+    assert gap_open >= gap_extend
+    n, m = len(s1), len(s2)
+    # per cell and state: (value, count, matches, length); the boundary is a start: value 0, one (empty) alignment
+    start = (0, 1, 0, 0)
+    none = (NEG, 0, 0, 0)
+
+    def merge(cands):
+        best = max(c[0] for c in cands)
+        if best <= NEG // 2:
+            return none
+        tied = [c for c in cands if c[0] == best and c[1] > 0]
+        cnt = min(2, sum(c[1] for c in tied))
+        return (best, cnt, tied[0][2], tied[0][3])
+    D = [[none] * (n + 1) for _ in range(m + 1)]
+    E = [[none] * (n + 1) for _ in range(m + 1)]
+    F = [[none] * (n + 1) for _ in range(m + 1)]
+    B = [[start if (i == 0 or j == 0) else none for i in range(n + 1)] for j in range(m + 1)]
+
+    def states(j, i):
+        return (B[j][i], D[j][i], E[j][i], F[j][i])
+    for j in range(1, m + 1):
+        for i in range(1, n + 1):
+            same = 1 if s1[i - 1].upper() == s2[j - 1].upper() else 0
+            w = score(s1[i - 1], s2[j - 1])
+            D[j][i] = merge([(v + w, c, a + same, l + 1) for (v, c, a, l) in states(j - 1, i - 1)])
+            b, d, e, f = states(j - 1, i)
+            E[j][i] = merge([(e[0] - gap_extend, e[1], e[2], e[3] + 1)] + [(v - gap_open, c, a, l + 1) for (v, c, a, l) in (b, d, f)])
+            b, d, e, f = states(j, i - 1)
+            F[j][i] = merge([(f[0] - gap_extend, f[1], f[2], f[3] + 1)] + [(v - gap_open, c, a, l + 1) for (v, c, a, l) in (b, d, e)])
+    border = [(j, n) for j in range(1, m + 1)] + [(m, i) for i in range(1, n)]
+    ends = []
+    for (j, i) in border:
+        h = merge(list(states(j, i)))
+        ends.append((h, i - 1, j - 1))
+    best = max(h[0] for h, _i, _j in ends)
+    tied = [(h, i, j) for h, i, j in ends if h[0] == best]
+    total = min(2, sum(h[1] for h, _i, _j in tied))
+    h, i, j = tied[0]
+    return total, (best, i, j, h[2], h[3])

@@ -130,8 +130,15 @@ def rank_main():
     real_make = bench.make_scanner
     bench.make_scanner = lambda workload, mode, kit_name, device: real_make(workload, mode, kit_name, 0)
 
-    def init_comm(ctx, r=None, w=None, environ=None):
-        return TcpComm(ctx, rank if r is None else r, world if w is None else w)
+    def init_comm(ctx, r=None, w=None, environ=None, trace=None):
+        for stage in parallel.COMM_STAGES[:2]:
+            if trace is not None:
+                trace(stage)
+        comm = TcpComm(ctx, rank if r is None else r, world if w is None else w)
+        for stage in parallel.COMM_STAGES[2:]:
+            if trace is not None:
+                trace(stage)
+        return comm
     parallel.init_comm = init_comm
     # the stub needs the bucket count of the kit bench.py builds
     real_kit = native.NativeKit

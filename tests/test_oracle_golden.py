@@ -250,3 +250,42 @@ def test_unequal_barcode_lengths_outside_simple_mode_are_a_value_error():
     lay2.barcode_set_1 = bs
     with pytest.raises(ValueError):
         native.KitDescriptor([lay2], qconfig.qcatConfig(), mode="epi2me")
+
+
+def _unique_cases():
+    import json
+    with open(os.path.join(helpers.GOLDEN, "sg_unique_vectors.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_statistics_on_unique_optimal_paths_need_no_tie_rule():
+    """tests/golden/sg_unique_vectors.json (make_sg_unique.py): 400 alignments with exactly ONE optimal path.  There
+    (matches, length) are facts of the inputs, so the oracle has to give them under EVERY rule of the shared switch --
+    these cases pin the two numbers to mathematics; only alignments with tied paths still rest on the recalled order."""
+    from qcat_amd import config as qconfig, native
+    cfg = qconfig.qcatConfig()
+    cases = _unique_cases()
+    assert len(cases) == 400 and sum(1 for c in cases if c["length"] != c["matches"]) >= 320
+    for c in cases:
+        tab = (cfg.matrix if c["matrix"] == "adapter" else cfg.matrix_barcode).table
+        want = (c["score"], c["end_query"], c["end_ref"], c["matches"], c["length"])
+        for rule in (native.STATS_PARASAIL6, native.STATS_PARASAIL5, native.STATS_ROUND3):
+            assert oracle_lib.sg_stats(c["query"], c["target"], c["open"], c["extend"], tab, rule=rule) == want, (c, rule)
+
+
+def test_path_count_dp_sees_ties():
+    """sg_independent.sg_unique_path on hand-made pairs: a deletion inside a homopolymer can sit in several places (not
+    unique), a clean embedded copy is unique."""
+    import sys
+    sys.path.insert(0, os.path.join(helpers.GOLDEN))
+    import sg_independent as si
+    from qcat_amd import config as qconfig
+    score = si.scorer_from_table7(qconfig.qcatConfig().matrix_barcode.table)
+    n, st = si.sg_unique_path("GGACGTTCAGG", "ACGTTCA", 1, 1, score)
+    assert n == 1 and st == (7, 8, 6, 7, 7)
+    n, _ = si.sg_unique_path("GGACAAATCAGG", "ACAAAATCA", 1, 1, score)       # one A short in a run of four: four placements
+    assert n == 2
+    n, _ = si.sg_unique_path("T", "GTCT", 1, 1, score)                         # best score shared by two border cells
+    assert n == 2
+    n, st = si.sg_unique_path("ACGT", "TTTT", 1, 1, score)                     # only the first target letter can pair with the last T
+    assert n == 1 and st == (1, 3, 0, 1, 1)

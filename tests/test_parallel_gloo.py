@@ -244,3 +244,38 @@ def test_bench_gpus8_on_a_small_box_fails_fast():
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode != 0 and b"--gpus 8 but only" in p.stderr and p.stdout.strip() == b""
     assert time.time() - t0 < 20.0            # (seconds of interpreter + library start, no scan: 2 s on a warm box)
+
+
+def test_comm_start_up_failure_names_rank_and_stage(monkeypatch):
+    """bench.py --gpus N: a rank that dies while the communicator is built says which of rendezvous /
+    ncclCommInitRank / first all-reduce it was in (parallel.init_comm), and traces the stages it entered."""
+    from qcat_amd import native, parallel
+
+    seen = []
+    monkeypatch.setattr(parallel, "exchange_id", lambda *a, **k: (_ for _ in ()).throw(OSError("no route")))
+    with pytest.raises(RuntimeError, match=r"rank 3 of 8 failed in stage 'rendezvous': no route"):
+        parallel.init_comm(None, 3, 8, environ={}, trace=seen.append)
+    assert seen == ["rendezvous"]
+
+    monkeypatch.setattr(parallel, "exchange_id", lambda *a, **k: b"\0" * 128)
+
+    class Dead:
+        def __init__(self, *a):
+            raise RuntimeError("ncclCommInitRank: unhandled system error")
+    monkeypatch.setattr(native, "NativeComm", Dead)
+    seen.clear()
+    with pytest.raises(RuntimeError, match=r"rank 1 of 2 failed in stage 'ncclCommInitRank'"):
+        parallel.init_comm(None, 1, 2, environ={}, trace=seen.append)
+    assert seen == ["rendezvous", "ncclCommInitRank"]
+
+    class Short:
+        def __init__(self, *a):
+            pass
+
+        def allreduce(self, values, op=0):
+            return [1.0]
+    monkeypatch.setattr(native, "NativeComm", Short)
+    seen.clear()
+    with pytest.raises(RuntimeError, match=r"failed in stage 'first all-reduce': all-reduce of one per rank gave 1.0 for 2 ranks"):
+        parallel.init_comm(None, 0, 2, environ={}, trace=seen.append)
+    assert seen == list(parallel.COMM_STAGES[:3])

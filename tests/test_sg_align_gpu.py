@@ -88,3 +88,25 @@ def test_helpers_agree_with_the_scanner_and_the_oracle():
         assert scanner_base.eval_adapter_template(lay, window, cfg, identity=False)[::2] == (o[1], o[0])
     assert scanner_base.align_adapter("", "ACGT", cfg) == (None, 0.0) and scanner_base.align_adapter_identity("ACGT", 4, "", 0, cfg) == (None, 0.0)
     assert scanner_base.find_highest_scoring_barcode("", det.layouts[0].get_barcode_set(0), cfg) == (None, 0, 0.0, -1)
+
+
+@pytest.mark.parametrize("stats", [True, native.STATS_PARASAIL5, native.STATS_ROUND3])
+def test_statistics_on_unique_optimal_paths(stats):
+    """tests/golden/sg_unique_vectors.json: alignments with exactly one optimal path (counted by the independent DP,
+    tests/golden/make_sg_unique.py).  All five numbers follow from the inputs alone, so the device kernel has to report
+    them under every rule of the QCAT_STATS_* switch: `matches` / `length` pinned by uniqueness, not by a tie order."""
+    import json
+    import os
+    with open(os.path.join(helpers.GOLDEN, "sg_unique_vectors.json")) as f:
+        cases = json.load(f)["cases"]
+    cfg = config.qcatConfig()
+    ctx = native.NativeContext(0)
+    for (go, ge) in sorted({(c["open"], c["extend"]) for c in cases}):
+        for name, matrix in (("adapter", cfg.matrix), ("barcode", cfg.matrix_barcode)):
+            sel = [c for c in cases if (c["open"], c["extend"]) == (go, ge) and c["matrix"] == name]
+            if not sel:
+                continue
+            got = native.sg_align(ctx, [c["query"] for c in sel], [c["target"] for c in sel], go, ge, matrix.table, with_stats=stats)
+            for i, c in enumerate(sel):
+                have = tuple(int(got[i][k]) for k in ("score", "end_query", "end_ref", "matches", "length"))
+                assert have == (c["score"], c["end_query"], c["end_ref"], c["matches"], c["length"]), (c, have)

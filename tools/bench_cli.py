@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""End-to-end rate of the driver (qcat_amd.cli) on a synthetic FASTQ file: native ingest (qcat_fastq_open: mmap + record
-splitting on the host threads) -> scan straight from the mapping -> native writers (qcat_fastq_demux), against the Python
-loop of the same driver (QCAT_AMD_NO_NATIVE_FASTQ=1: Python parser, batches of 4000, Python writers).
+"""End-to-end rate of the driver (qcat_amd.cli) on a synthetic FASTQ file: the native file loop (qcat_fastq_demux_stream:
+segments of the file through read | scan | write) against the Python loop of the same driver (QCAT_AMD_NO_NATIVE_FASTQ=1:
+Python parser, batches of 4000, Python writers), with and without --detect-middle / --filter-barcodes.
 
     python tools/bench_cli.py [reads, default 2000000] [python-loop reads, default 100000]
 
@@ -54,7 +54,7 @@ def write_fastq(path, count):
             fh.write(b"\n")
 
 
-def run(fq, kitname, out, tsv, native_path, tsv_file=None):
+def run(fq, kitname, out, tsv, native_path, tsv_file=None, middle=False, filt=False):
     """one run of the driver; the TSV goes to a StringIO (compared by the caller) or, at size, to a file like the shell's `> calls.tsv`"""
     if native_path:
         os.environ.pop("QCAT_AMD_NO_NATIVE_FASTQ", None)
@@ -64,7 +64,7 @@ def run(fq, kitname, out, tsv, native_path, tsv_file=None):
     t0 = time.perf_counter()
     dist = cli.qcat_cli(reads_fq=fq, kit=kitname, mode="epi2me", nobatch=False, out=out, min_qual=None, tsv=tsv,
                         output=None if (out or tsv) else os.path.join(tmp, "stream.fastq"), threads=1, trim=True, adapter_yaml=None,
-                        quiet=True, filter_barcodes=False, middle_adapter=False, min_read_length=100,
+                        quiet=True, filter_barcodes=filt, middle_adapter=middle, min_read_length=100,
                         qcat_config=config.get_default_config(), tsv_stream=buf)
     dt = time.perf_counter() - t0
     if tsv_file:
@@ -95,6 +95,14 @@ for kitname in ("PBC096", "auto"):
     same = same and tsv_py == tsv_nat
     res["kit_%s_%d_reads" % (kitname, n_py)] = {"python_loop_reads_per_s": round(n_py / dt_py, 1), "native_reads_per_s": round(n_py / dt_nat, 1)}
 res["outputs_identical"] = bool(same)
+# ---- the same with the driver's two per-read / per-batch flags (round 5: both on the native loop) ----------------------
+same_flags = True
+for label, kw in (("detect_middle", {"middle": True}), ("filter_barcodes", {"filt": True}), ("both", {"middle": True, "filt": True})):
+    dt_py, dist_py, tsv_py = run(small, "PBC096", None, True, False, **kw)
+    dt_nat, dist_nat, tsv_nat = run(small, "PBC096", None, True, True, **kw)
+    same_flags = same_flags and tsv_py == tsv_nat and dist_py == dist_nat
+    res["flags_%s_%d_reads" % (label, n_py)] = {"python_loop_reads_per_s": round(n_py / dt_py, 1), "native_reads_per_s": round(n_py / dt_nat, 1)}
+res["outputs_identical_with_flags"] = bool(same_flags)
 # ---- the native path at size: TSV (calls only) and per-barcode FASTQ files (the whole file is written again) ----------
 big = os.path.join(tmp, "big.fastq")
 write_fastq(big, n)
@@ -113,22 +121,25 @@ res["ingest"] = {"file_gb": round(size / 1e9, 3), "open_s": round(best, 4), "par
 for label, out, tsv in (("tsv", None, True), ("per_barcode_fastq", os.path.join(tmp, "big_out"), False)):
     dt = min(run(big, "PBC096", out, tsv, True, tsv_file=os.path.join(tmp, "big.tsv") if tsv else None)[0] for _ in range(2))
     res["native_" + label] = {"reads_per_s": round(n / dt, 1), "seconds": round(dt, 3)}
-    # the split of one more run, from the library's own clock
-    fq = native.FastqFile(big)
+    # the split of one more run, from the library's own clock (busy seconds per stage; the stages run side by side)
     sink = tempfile.TemporaryFile()
     if out and not os.path.exists(out):
         os.makedirs(out)
-    _, _, st = fq.demux(ctx, kit, det.layouts, False, kit_auto=False, trim=True, min_read_length=100,
-                        tsv_fd=sink.fileno() if tsv else None, out_fd=None, out_dir=out)
-    fq.close()
+    st = native.FastqFile.demux_stream(big, ctx, kit, det.layouts, False, kit_auto=False, trim=True, min_read_length=100,
+                                       tsv_fd=sink.fileno() if tsv else None, out_fd=None, out_dir=out)[4]
     sink.close()
     res["native_" + label]["split_s"] = {k: round(st[k], 4) for k in ("parse_s", "scan_s", "write_s", "total_s")}
+    res["native_" + label]["segments"] = st["segments"]
+for label, kw in (("detect_middle", {"middle": True}), ("filter_barcodes", {"filt": True})):
+    dt = min(run(big, "PBC096", None, True, True, tsv_file=os.path.join(tmp, "big_flags.tsv"), **kw)[0] for _ in range(2))
+    res["native_tsv_" + label] = {"reads_per_s": round(n / dt, 1), "seconds": round(dt, 3)}
 # ---- the driver's DEFAULT: kit auto, one vote per batch of 4000 reads (qcat/cli.py:500) -- every batch a call of its own;
 #      round 4: chunks of 64 batches per call (qcat_scan_batches_auto_ptrs: one vote per batch on the device), reads as pointers into the mapping
 for label, chunk in (("one_call_per_batch", "1"), ("default", None)):          # (round 3's loop; chunks of 64 batches per call)
     native.set_option("AUTO_CHUNK", int(chunk) if chunk else None)
     dt = min(run(big, "auto", None, True, True, tsv_file=os.path.join(tmp, "big_auto.tsv"))[0] for _ in range(2))
     res["native_tsv_kit_auto_" + label] = {"reads_per_s": round(n / dt, 1), "seconds": round(dt, 3)}
-res["note"] = ("host-bound: the file is split at parse_gb_per_s on the host threads, the scan reads heads and tails of the reads in "
-               "place, the writers format on the host threads beside the scan (total_s = the demux call, seconds = the whole driver run incl. context set-up); per-barcode FASTQ output rewrites every byte of the input")
+res["note"] = ("host-bound: segments of the file are split on the host threads, the scan reads heads and tails of the reads in place "
+               "(whole reads with --detect-middle), the writer formats beside the scan (total_s = the demux call, seconds = the whole "
+               "driver run incl. context set-up); per-barcode FASTQ output rewrites every byte of the input")
 print(json.dumps(res))
