@@ -33,6 +33,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import resource
 import sys
 import time
 
@@ -288,6 +289,17 @@ def main():
         comm.close()
 
 
+def cgroup_cpu_stat():
+    """(periods, throttled periods, throttled microseconds) of this container's CPU controller (cgroup v2 cpu.stat): whether
+    the host threads of a leg were stalled by the CPU quota while it ran (None where the file is absent)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as fh:
+            kv = dict(line.split() for line in fh if line.strip())
+        return int(kv.get("nr_periods", 0)), int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+    except (IOError, ValueError):
+        return None
+
+
 def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
     """The same reads from a FASTQ FILE: qcat_fastq_open (mmap + record splitting on the host threads) and
     qcat_fastq_demux (scan straight from the mapping, TSV written beside the scan) on the first min(n, 1 M) reads,
@@ -324,12 +336,17 @@ def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
     stream_best = None
     stream_ok = True
     sink2 = open(os.path.join(tmp, "stream.tsv"), "w+b")
+    throttle = None
     for reader in (0, 0, 0):                         # (the library's default reader: mapped windows)
         sink2.seek(0)
+        cs0 = cgroup_cpu_stat()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t1 = time.perf_counter()
         bc, ad, none, ad_none, st2 = native.FastqFile.demux_stream(path, ctx, kit, det.layouts, mode == "dual", kit_auto=False, trim=True,
                                                                     min_read_length=0, tsv_fd=sink2.fileno(), reader=reader)
         dt2 = time.perf_counter() - t1
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        cs1 = cgroup_cpu_stat()
         sink2.seek(0)
         stream_ok = stream_ok and sink2.read(len(want_tsv) + 1) == want_tsv
         called = (got["barcode_idx"] >= 0) & (got["adapter_idx"] >= 0) & ((got["barcode2_idx"] >= 0) | (mode != "dual"))
@@ -337,6 +354,11 @@ def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
             and st2["n_reads"] == m and not st2["incomplete"]
         if stream_best is None or dt2 < stream_best[0]:
             stream_best = (dt2, st2, reader)
+            throttle = {"cpu_s": round((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime), 3),
+                        "of_which_system_s": round(ru1.ru_stime - ru0.ru_stime, 3),
+                        "cgroup_periods": cs1[0] - cs0[0] if cs0 and cs1 else None,
+                        "cgroup_throttled_periods": cs1[1] - cs0[1] if cs0 and cs1 else None,
+                        "cgroup_throttled_ms": round((cs1[2] - cs0[2]) / 1e3, 2) if cs0 and cs1 else None}
     sink2.close()
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))
@@ -348,7 +370,7 @@ def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
     dt, st = best
     dt2, st2, reader = stream_best
     return {"value": round(m / dt2, 1), "unit": "reads/s", "reads": m, "file_gb": round(size / 1e9, 3),
-            "stream": {"reader": "mapped windows", "segments": st2["segments"],
+            "stream": {"reader": "mapped windows", "segments": st2["segments"], "host": throttle,
                        "split_s": {k: round(st2[k], 4) for k in ("parse_s", "scan_s", "write_s", "total_s")}},
             "whole_file": {"value": round(m / dt, 1), "parse_gb_per_s": round(size / st["parse_s"] / 1e9, 2),
                            "split_s": {k: round(st[k], 4) for k in ("parse_s", "scan_s", "write_s", "total_s")}},

@@ -44,6 +44,8 @@ static PyObject* read_views(PyObject* self, PyObject* arg) {
 typedef struct { int16_t barcode_idx, barcode2_idx, adapter_idx, exit_status; int32_t adapter_end, trim5p, trim3p; int16_t raw_score, score_den; } rec_t;
 
 static PyObject *k_barcode, *k_score, *k_adapter, *k_end, *k_t5, *k_t3, *k_exit;
+static PyObject* dict_template;          /* the seven keys in the reference's order, values None: a result dict starts as a copy (public API,
+                                          one allocation of the right size; PyDict_New() grows at the sixth key) */
 
 static PyObject* records_to_dicts(PyObject* self, PyObject* args) {
     (void)self;
@@ -76,7 +78,7 @@ static PyObject* records_to_dicts(PyObject* self, PyObject* args) {
         /* the same IEEE double expression as qcat/scanner_base.py:119: raw * 100.0 / (1.0 * den) */
         const double den = r[i].score_den > 1 ? (double)r[i].score_den : 1.0;
         const double score = b > 0 ? (double)r[i].raw_score * 100.0 / (1.0 * den) : 0.0;
-        PyObject* d = PyDict_New();            
+        PyObject* d = PyDict_Copy(dict_template);
         PyObject* v_score = PyFloat_FromDouble(score);
         PyObject* v_end = PyLong_FromLong(r[i].adapter_end);
         PyObject* v_t5 = PyLong_FromLong(r[i].trim5p);
@@ -112,5 +114,12 @@ PyMODINIT_FUNC PyInit__pyglue(void) {
     k_t5 = PyUnicode_InternFromString("trim5p"); k_t3 = PyUnicode_InternFromString("trim3p");
     k_exit = PyUnicode_InternFromString("exit_status");
     if (!k_barcode || !k_score || !k_adapter || !k_end || !k_t5 || !k_t3 || !k_exit) return NULL;
+    dict_template = PyDict_New();
+    if (!dict_template) return NULL;
+    {
+        PyObject* keys[7] = {k_barcode, k_score, k_adapter, k_end, k_t5, k_t3, k_exit};
+        for (int i = 0; i < 7; ++i)
+            if (PyDict_SetItem(dict_template, keys[i], Py_None) < 0) return NULL;
+    }
     return PyModule_Create(&module);
 }
