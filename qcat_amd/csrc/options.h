@@ -67,6 +67,7 @@
     X(NO_PIPELINE, "1: no chunked host pipeline") \
     X(PIPELINE_CHUNK, "reads per chunk of the host pipeline") \
     X(PIPELINE_TRACE, "1: print the split of a pipelined call") \
+    X(STREAM_SYNC_RELEASE, "1: the file loop's reader gives a written segment's pages back itself (A/B: a thread of its own)") \
     X(AUTO_CHUNK, "batches per call of the kit-auto file loop") \
     X(AUTO_WORKERS, "contexts of the kit-auto file loop") \
     X(NO_GRAPH, "1: host-buffer calls never replay a captured graph") \

@@ -1,11 +1,13 @@
 #!/bin/bash
+# kernel + copy timeline of single-read calls (bench.py --workload api1 under rocprofv3 --kernel-trace --memory-copy-trace):
+# gpurun_out/api1_trace/timeline.txt = 70 consecutive events of the named-kit leg with start offsets and durations
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/r05_api1
+out=$R/gpurun_out/api1_trace
 mkdir -p $out
 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/rp_api1 -o t --output-format csv -- python $R/bench.py --workload api1 --steps 1 --reads 300 > $out/trace_run.log 2>&1
 ls /tmp/rp_api1/*/ | head
-python - <<'PY'
+python - > $out/timeline.txt <<'PY'
 import csv, glob
 k = glob.glob('/tmp/rp_api1/**/*kernel_trace.csv', recursive=True)[0]
 m = glob.glob('/tmp/rp_api1/**/*memory_copy_trace.csv', recursive=True)[0]
@@ -23,3 +25,5 @@ t0 = ev[i0][0]
 for s, e, name in ev[i0:i0 + 70]:
     print("%9.1f us  +%7.1f us  %s" % ((s - t0) / 1e3, (e - s) / 1e3, name))
 PY
+
+tail -72 $out/timeline.txt
