@@ -310,10 +310,21 @@ def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
     path = os.path.join(tmp, "reads.fastq")
     raw = hb[:int(ho[m])].tobytes()
     qual = b"I" * 65536
-    with open(path, "wb") as fh:
-        for i in range(m):
-            s = raw[int(ho[i]):int(ho[i + 1])]
-            fh.write(b"@r%d ch=%d\n%s\n+\n%s\n" % (i, 1 + i % 512, s, qual[:len(s)] if len(s) <= 65536 else b"I" * len(s)))
+    # written in pieces of 16 k reads (~25 MB) -- the way a basecaller, `cat` or a copy writes a file: the page cache then holds it
+    # in large folios.  A file written by a million 1.5 KB writes sits in single 4 KB pages, and every mapping operation on it
+    # (populate, fault-around, zap) costs 3-10 x as much per byte: QCAT_BENCH_SMALL_WRITES=1 measures that case
+    small_writes = os.environ.get("QCAT_BENCH_SMALL_WRITES") == "1"
+    with open(path, "wb", buffering=0) as fh:
+        for i0 in range(0, m, 16384):
+            piece = []
+            for i in range(i0, min(m, i0 + 16384)):
+                s = raw[int(ho[i]):int(ho[i + 1])]
+                piece.append(b"@r%d ch=%d\n%s\n+\n%s\n" % (i, 1 + i % 512, s, qual[:len(s)] if len(s) <= 65536 else b"I" * len(s)))
+            if small_writes:
+                for rec in piece:
+                    fh.write(rec)
+            else:
+                fh.write(b"".join(piece))
     size = os.path.getsize(path)
     native.FastqFile(path).close()                   # (page cache warm, as after the file was just written)
     best = None
@@ -337,7 +348,8 @@ def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
     stream_ok = True
     sink2 = open(os.path.join(tmp, "stream.tsv"), "w+b")
     throttle = None
-    for reader in (0, 0, 0):                         # (the library's default reader: mapped windows)
+    runs_ms = []
+    for reader in (0,) * max(1, int(os.environ.get("QCAT_BENCH_STREAM_REPEATS", "3"))):     # (the library's default reader: mapped windows)
         sink2.seek(0)
         cs0 = cgroup_cpu_stat()
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
@@ -347,6 +359,7 @@ def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
         dt2 = time.perf_counter() - t1
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         cs1 = cgroup_cpu_stat()
+        runs_ms.append(round(dt2 * 1e3, 2))
         sink2.seek(0)
         stream_ok = stream_ok and sink2.read(len(want_tsv) + 1) == want_tsv
         called = (got["barcode_idx"] >= 0) & (got["adapter_idx"] >= 0) & ((got["barcode2_idx"] >= 0) | (mode != "dual"))
@@ -370,7 +383,7 @@ def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
     dt, st = best
     dt2, st2, reader = stream_best
     return {"value": round(m / dt2, 1), "unit": "reads/s", "reads": m, "file_gb": round(size / 1e9, 3),
-            "stream": {"reader": "mapped windows", "segments": st2["segments"], "host": throttle,
+            "stream": {"reader": "mapped windows", "segments": st2["segments"], "runs_ms": runs_ms, "host": throttle,
                        "split_s": {k: round(st2[k], 4) for k in ("parse_s", "scan_s", "write_s", "total_s")}},
             "whole_file": {"value": round(m / dt, 1), "parse_gb_per_s": round(size / st["parse_s"] / 1e9, 2),
                            "split_s": {k: round(st[k], 4) for k in ("parse_s", "scan_s", "write_s", "total_s")}},

@@ -17,13 +17,13 @@ for r in csv.DictReader(open(k)):
 for r in csv.DictReader(open(m)):
     ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r.get('Direction', r.get('Name', ''))[:40] ))
 ev.sort()
-# the last named-kit call: find a window of events near 60% of the run
+# two windows: inside the named-kit leg (the first 300 calls) and inside the kit-auto leg (the last 300)
 n = len(ev)
-i0 = n // 3
-# print 60 consecutive events with gaps
-t0 = ev[i0][0]
-for s, e, name in ev[i0:i0 + 70]:
-    print("%9.1f us  +%7.1f us  %s" % ((s - t0) / 1e3, (e - s) / 1e3, name))
+for label, i0 in (("named kit", n // 6), ("kit auto", 3 * n // 4)):
+    print("---- " + label)
+    t0 = ev[i0][0]
+    for s, e, name in ev[i0:i0 + 60]:
+        print("%9.1f us  +%7.1f us  %s" % ((s - t0) / 1e3, (e - s) / 1e3, name))
 PY
 
-tail -72 $out/timeline.txt
+head -64 $out/timeline.txt

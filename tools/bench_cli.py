@@ -44,7 +44,9 @@ def write_fastq(path, count):
     lib.qcat_batch_destroy(b)
     raw = bases.tobytes()
     qual = b"I" * 4096
-    with open(path, "wb") as fh:
+    # (a 32 MB buffer: the file reaches the page cache in large pieces, as a basecaller or a copy writes it -- a file that
+    #  arrives in 8 KB writes sits in single pages and every mapping operation on it costs several times as much)
+    with open(path, "wb", buffering=32 << 20) as fh:
         for i in range(count):
             s = raw[int(offs[i]):int(offs[i + 1])]
             fh.write(b"@read%d runid=bench ch=%d\n" % (i, 1 + i % 512))

@@ -1,7 +1,13 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out/r05_check
-timeout 1500 python -m pytest tests -x -q -m gpu -k "unique or middle or comm or stream or cli or fastq or api" > gpurun_out/r05_check/tests.log 2>&1; tail -3 gpurun_out/r05_check/tests.log
-for wl in api4000 middle; do timeout 600 python bench.py --workload $wl > gpurun_out/r05_check/bench_$wl.json 2>/dev/null; python -c "
-import json; d=json.load(open('gpurun_out/r05_check/bench_$wl.json')); print('$wl', d['value'], d['ms_per_step'], d.get('split_ms_per_call'))"; done
-bash tools/stream_diag.sh
+for v in 0 1; do
+QCAT_BENCH_SMALL_WRITES=$v QCAT_BENCH_STREAM_REPEATS=6 timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --reads 1000000 > gpurun_out/r05_check/bench_writes$v.json 2>/dev/null
+python - $v <<'PY'
+import json, sys
+d = json.load(open("gpurun_out/r05_check/bench_writes%s.json" % sys.argv[1]))
+f = d["host_inclusive"]["from_fastq"]
+print("small_writes", sys.argv[1], f["value"], f["stream"], f["whole_file"]["value"])
+PY
+done
+grep -i "AnonHugePages\|FileHugePages\|ShmemHuge" /proc/meminfo; cat /sys/kernel/mm/transparent_hugepage/enabled; df -T /tmp | tail -1
