@@ -388,6 +388,10 @@ int64_t qcat_ctx_graph_replays(const qcat_ctx* ctx);
  * front, ABI 5), out[1] = nominal regions, out[2] = full windows; all zero when the batch was too small for the path.
  * Synchronises the context's stream.  Tests and diagnostics. */
 int qcat_ctx_barcode_bitslice_tiles(qcat_ctx* ctx, uint32_t out[3]);
+/* Read ends the context's latest scan put on the one-wave-per-alignment kernels (csrc/kernels_tiny.inc: batches of a handful of
+ * reads -- BarcodeScanner.detect_barcode on one read, qcat/scanner_base.py:521-604); 0: the scan took another path; -1: null
+ * context.  Tests and diagnostics. */
+int64_t qcat_ctx_tiny_ends(const qcat_ctx* ctx);
 
 /* Diagnostics of the context's latest --detect-middle scan (detect_barcode's interior scan, qcat/scanner_base.py:479-519,
  * :593-595): out[0] = tiles of 2048 interiors whose adapter scan ran in bit-sliced form (csrc/kernels_abs_mid.inc), out[1] =

@@ -28,6 +28,7 @@
 #include "kit_prepare.inc"
 #include "kernels_common.inc"
 #include "kernels_generic.inc"
+#include "kernels_tiny.inc"
 #include "kernels_packed.inc"
 #include "kernels_bitslice.inc"
 #include "packed_host.inc"
@@ -512,6 +513,9 @@ struct qcat_ctx {
         int failures = 0;                                                         // captures that did not work out (two: never again)
         uint64_t replays = 0;
     } api_graph, scan_graph;                       // kit-auto calls (scan_batch_auto_impl); calls with a named kit (qcat_scan_batch, round 5)
+    // the handful-of-reads path (kernels_tiny.inc): per read end the templates' (raw, end) and the barcodes' raw scores
+    int32_t* tiny_tpl = nullptr; int16_t* tiny_sc = nullptr; size_t cap_tiny = 0; uint32_t tiny_stride = 0;
+    uint32_t last_tiny_ends = 0;                   // read ends the last scan put on that path (0: another path)
     // debug buffers
     int32_t* dbg_tpl = nullptr; size_t cap_dbg_tpl = 0;
     int16_t* dbg_rows = nullptr; size_t cap_dbg_rows = 0;
@@ -554,7 +558,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     if (c->api_graph.exec) (void)hipGraphExecDestroy(c->api_graph.exec);
     if (c->scan_graph.exec) (void)hipGraphExecDestroy(c->scan_graph.exec);
     (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->wspec); (void)hipFree(c->win2); (void)hipFree(c->recs); (void)hipFree(c->results);
-    (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows);
+    (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows); (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc);
     (void)hipFree(c->hb_bases); (void)hipFree(c->hb_offsets); (void)hipFree(c->hb_len); (void)hipFree(c->vote_buf);
     packed_scratch_free(&c->packed);
     if (c->pin_bases) (void)hipHostFree(c->pin_bases);
@@ -885,13 +889,34 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     }
     // the fills of a scan leave as ONE launch in front of the pack kernel (k_fill_multi): count vector, letter flags, and --
     // with the job tables and the adapter tile flags sized here instead of after the pack kernel -- theirs too
-    const bool use_packed = hk.fast_ok && !c->force_generic && packed_supported(hk);
+    const bool packed_kit = hk.fast_ok && !c->force_generic && packed_supported(hk);
+    bool use_packed = packed_kit;
+    // a handful of read ends (detect_barcode on one read, a few reads of a test): one wave per alignment, kernels_tiny.inc
+    // (QCAT_HIP_TINY_MAX_ENDS: the largest batch that goes there, 0: none; QCAT_HIP_NO_TINY=1)
+    const QOptVal tiny_env = qopt_get(QO_TINY_MAX_ENDS);
+    const uint64_t tiny_max = opt_on(QO_NO_TINY) ? 0 : (tiny_env ? (uint64_t)std::max<long long>(0, atoll(tiny_env)) : (uint64_t)TINY_MAX_ENDS_DEFAULT);
+    const bool tiny = n_ends > 0 && n_ends <= std::min<uint64_t>(tiny_max, 4096) && hk.mode != QCAT_MODE_SIMPLE && resume_kit_mask < 0 &&
+                      !adapter_only && !c->force_generic && hk.gap_open == hk.gap_extend;
+    c->last_tiny_ends = tiny ? (uint32_t)n_ends : 0;
+    int tiny_maxb = 1;
+    if (tiny) {
+        for (int t = 0; t < hk.nt; ++t) for (int s2 = 0; s2 < 2; ++s2) tiny_maxb = std::max(tiny_maxb, (int)hk.tpl[t].sets[s2].n);
+        const size_t need = (size_t)n_ends * 2 * (size_t)tiny_maxb;
+        if (need > c->cap_tiny || !c->tiny_tpl) {
+            (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc); c->tiny_tpl = nullptr; c->tiny_sc = nullptr; c->cap_tiny = 0;
+            const size_t cap = std::max<size_t>(need, (size_t)TINY_MAX_ENDS_DEFAULT * 2 * 96);
+            HIPCHK(q_malloc((void**)&c->tiny_sc, cap * sizeof(int16_t)));
+            HIPCHK(q_malloc((void**)&c->tiny_tpl, std::max<size_t>((size_t)n_ends, 4096) * MAX_T * 2 * sizeof(int32_t)));
+            c->cap_tiny = cap;
+        }
+        use_packed = false;                        // (no job tables, no lazy windows: the tiny kernels read byte windows)
+    }
     g_fill_defer = n != 0 && !opt_on(QO_NO_FILL_MERGE);
     if (!keep_counts) HIPCHK(packed_fill(c->counts, 0, (size_t)hk.n_buckets * 8, c->stream));
     if (n == 0) { HIPCHK(packed_fill_flush(c->stream)); return 0; }
     if (c->timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));   // (an empty batch returned above: its slot holds no marks)
     c->absm_codes_early = false;
-    if (hk.scan_middle && !adapter_only && use_packed && middle_packed_ok(hk) && (rc = absmid_codes_early(c, hk, b, n))) return rc;
+    if (hk.scan_middle && !adapter_only && packed_kit && middle_packed_ok(hk) && (rc = absmid_codes_early(c, hk, b, n))) return rc;
 
     KitPtrs kp{kd->kit, kd->codes, kd->ids, kd->tables};
     g_jit = kd;
@@ -964,6 +989,14 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
                          debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride,
                          [&](const char* nm) { mark(c, nm); }, adapter_only, resume_kit_mask);
         if (rc) return set_err(rc, packed_last_error());
+    } else if (tiny) {
+        TinyArgs ta{kp, c->win, c->wlen, (uint32_t)n_ends, c->recs, c->tiny_tpl, c->tiny_sc, (uint32_t)tiny_maxb,
+                    debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride, 0};
+        hipLaunchKernelGGL(k_tiny_adapter, dim3((uint32_t)n_ends * (uint32_t)hk.nt), dim3(64), 0, c->stream, ta);
+        hipLaunchKernelGGL(k_tiny_decide, dim3((uint32_t)((n_ends + 63) / 64)), dim3(64), 0, c->stream, ta);
+        hipLaunchKernelGGL(k_tiny_barcode, dim3((uint32_t)tiny_maxb, (uint32_t)n_ends * 2), dim3(64), 0, c->stream, ta);
+        hipLaunchKernelGGL(k_tiny_select, dim3((uint32_t)((n_ends * 2 + 63) / 64)), dim3(64), 0, c->stream, ta);
+        mark(c, "k_scan_tiny");
     } else {
         uint32_t blocks = (uint32_t)((n_ends + GEN_THREADS - 1) / GEN_THREADS);
         hipLaunchKernelGGL(k_scan_generic, dim3(blocks), dim3(GEN_THREADS), 0, c->stream,
@@ -985,7 +1018,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         mark(c, "k_finalize");
         if (middle) {
             const uint8_t* only = nullptr;
-            if (use_packed && middle_packed_ok(hk)) {
+            if (packed_kit && middle_packed_ok(hk)) {              // (also after the tiny kernels: the interiors are no handful of cells)
                 if ((rc = middle_packed(c, kp, hk, b, n))) return rc;
                 only = c->mid_generic;                  // interiors beyond the packed path's length classes
                 mark(c, "k_middle_packed");
@@ -1030,6 +1063,7 @@ extern "C" int qcat_ctx_fetch_counts(qcat_ctx* c, int64_t* counts, int32_t n_buc
 }
 
 extern "C" void* qcat_ctx_stream(qcat_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int64_t qcat_ctx_tiny_ends(const qcat_ctx* c) { return c ? (int64_t)c->last_tiny_ends : -1; }
 extern "C" int64_t qcat_ctx_graph_replays(const qcat_ctx* c) { return c ? (int64_t)(c->api_graph.replays + c->scan_graph.replays) : -1; }
 // diagnostics of the latest scan of the read ends: super-tiles (2048 barcode alignments each) its bit-sliced barcode kernels took, per
 // hot class summed over the (template, set) groups -- out[0] regions a few bases short of nominal (front-padded units), out[1]

@@ -62,16 +62,16 @@ def _forward_switches_to_the_option_abi():
             saved[opt] = native.get_option(opt)
 
     def setenv(self, name, value, prepend=None):
+        opt = option_of(name)          # (first: this may LOAD the library, which imports QCAT_HIP_* from the environment as it is then)
         orig_setenv(self, name, value, prepend)
-        opt = option_of(name)
         if opt:
             from qcat_amd import native
             remember(self, opt)
             native.set_option(opt, int(value) if str(value).strip() else 1)
 
     def delenv(self, name, raising=True):
-        orig_delenv(self, name, raising)
         opt = option_of(name)
+        orig_delenv(self, name, raising)
         if opt:
             from qcat_amd import native
             remember(self, opt)
