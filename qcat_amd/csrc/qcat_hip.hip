@@ -995,7 +995,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         hipLaunchKernelGGL(k_tiny_adapter, dim3((uint32_t)n_ends * (uint32_t)hk.nt), dim3(64), 0, c->stream, ta);
         hipLaunchKernelGGL(k_tiny_decide, dim3((uint32_t)((n_ends + 63) / 64)), dim3(64), 0, c->stream, ta);
         hipLaunchKernelGGL(k_tiny_barcode, dim3((uint32_t)tiny_maxb, (uint32_t)n_ends * 2), dim3(64), 0, c->stream, ta);
-        hipLaunchKernelGGL(k_tiny_select, dim3((uint32_t)((n_ends * 2 + 63) / 64)), dim3(64), 0, c->stream, ta);
+        hipLaunchKernelGGL(k_tiny_select, dim3((uint32_t)n_ends * 2), dim3(64), 0, c->stream, ta);
         mark(c, "k_scan_tiny");
     } else {
         uint32_t blocks = (uint32_t)((n_ends + GEN_THREADS - 1) / GEN_THREADS);
