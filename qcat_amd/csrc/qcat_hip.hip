@@ -514,7 +514,7 @@ struct qcat_ctx {
         uint64_t replays = 0;
     } api_graph, scan_graph;                       // kit-auto calls (scan_batch_auto_impl); calls with a named kit (qcat_scan_batch, round 5)
     // the handful-of-reads path (kernels_tiny.inc): per read end the templates' (raw, end) and the barcodes' raw scores
-    int32_t* tiny_tpl = nullptr; int16_t* tiny_sc = nullptr; uint32_t* tiny_done = nullptr; size_t cap_tiny = 0;
+    int32_t* tiny_tpl = nullptr; int16_t* tiny_sc = nullptr; size_t cap_tiny = 0; uint32_t tiny_stride = 0;
     uint32_t last_tiny_ends = 0;                   // read ends the last scan put on that path (0: another path)
     // debug buffers
     int32_t* dbg_tpl = nullptr; size_t cap_dbg_tpl = 0;
@@ -558,7 +558,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     if (c->api_graph.exec) (void)hipGraphExecDestroy(c->api_graph.exec);
     if (c->scan_graph.exec) (void)hipGraphExecDestroy(c->scan_graph.exec);
     (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->wspec); (void)hipFree(c->win2); (void)hipFree(c->recs); (void)hipFree(c->results);
-    (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows); (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc); (void)hipFree(c->tiny_done);
+    (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows); (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc);
     (void)hipFree(c->hb_bases); (void)hipFree(c->hb_offsets); (void)hipFree(c->hb_len); (void)hipFree(c->vote_buf);
     packed_scratch_free(&c->packed);
     if (c->pin_bases) (void)hipHostFree(c->pin_bases);
@@ -903,9 +903,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
         for (int t = 0; t < hk.nt; ++t) for (int s2 = 0; s2 < 2; ++s2) tiny_maxb = std::max(tiny_maxb, (int)hk.tpl[t].sets[s2].n);
         const size_t need = (size_t)n_ends * 2 * (size_t)tiny_maxb;
         if (need > c->cap_tiny || !c->tiny_tpl) {
-            (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc); (void)hipFree(c->tiny_done);
-            c->tiny_tpl = nullptr; c->tiny_sc = nullptr; c->tiny_done = nullptr; c->cap_tiny = 0;
-            HIPCHK(q_malloc((void**)&c->tiny_done, 4096 * 2 * sizeof(uint32_t)));
+            (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc); c->tiny_tpl = nullptr; c->tiny_sc = nullptr; c->cap_tiny = 0;
             const size_t cap = std::max<size_t>(need, (size_t)TINY_MAX_ENDS_DEFAULT * 2 * 96);
             HIPCHK(q_malloc((void**)&c->tiny_sc, cap * sizeof(int16_t)));
             HIPCHK(q_malloc((void**)&c->tiny_tpl, std::max<size_t>((size_t)n_ends, 4096) * MAX_T * 2 * sizeof(int32_t)));
@@ -915,7 +913,6 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     }
     g_fill_defer = n != 0 && !opt_on(QO_NO_FILL_MERGE);
     if (!keep_counts) HIPCHK(packed_fill(c->counts, 0, (size_t)hk.n_buckets * 8, c->stream));
-    if (tiny) HIPCHK(packed_fill(c->tiny_done, 0, (size_t)n_ends * 2 * sizeof(uint32_t), c->stream));
     if (n == 0) { HIPCHK(packed_fill_flush(c->stream)); return 0; }
     if (c->timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));   // (an empty batch returned above: its slot holds no marks)
     c->absm_codes_early = false;
@@ -993,10 +990,12 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
                          [&](const char* nm) { mark(c, nm); }, adapter_only, resume_kit_mask);
         if (rc) return set_err(rc, packed_last_error());
     } else if (tiny) {
-        TinyArgs ta{kp, c->win, c->wlen, (uint32_t)n_ends, c->recs, c->tiny_tpl, c->tiny_sc, (uint32_t)tiny_maxb, c->tiny_done,
+        TinyArgs ta{kp, c->win, c->wlen, (uint32_t)n_ends, c->recs, c->tiny_tpl, c->tiny_sc, (uint32_t)tiny_maxb,
                     debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride, 0};
         hipLaunchKernelGGL(k_tiny_adapter, dim3((uint32_t)n_ends * (uint32_t)hk.nt), dim3(64), 0, c->stream, ta);
+        hipLaunchKernelGGL(k_tiny_decide, dim3((uint32_t)((n_ends + 63) / 64)), dim3(64), 0, c->stream, ta);
         hipLaunchKernelGGL(k_tiny_barcode, dim3((uint32_t)tiny_maxb, (uint32_t)n_ends * 2), dim3(64), 0, c->stream, ta);
+        hipLaunchKernelGGL(k_tiny_select, dim3((uint32_t)n_ends * 2), dim3(64), 0, c->stream, ta);
         mark(c, "k_scan_tiny");
     } else {
         uint32_t blocks = (uint32_t)((n_ends + GEN_THREADS - 1) / GEN_THREADS);
