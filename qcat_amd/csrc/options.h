@@ -69,7 +69,7 @@
     X(PIPELINE_TRACE, "1: print the split of a pipelined call") \
     X(ABS_SERIAL, "1: the bit-sliced adapter launches of a scan one after the other instead of side by side (A/B)") \
     X(NO_TINY, "1: batches of a handful of read ends take the throughput kernels like every other batch") \
-    X(TINY_MAX_ENDS, "largest batch (read ends) on the one-wave-per-alignment kernels (default 64, 0: none)") \
+    X(TINY_MAX_ENDS, "largest batch (read ends, at most 4096) on the one-wave-per-alignment kernels (default: by the number of alignments, 20000)") \
     X(STREAM_SYNC_RELEASE, "1: the file loop's reader gives a written segment's pages back itself (A/B: a thread of its own)") \
     X(AUTO_CHUNK, "batches per call of the kit-auto file loop") \
     X(AUTO_WORKERS, "contexts of the kit-auto file loop") \

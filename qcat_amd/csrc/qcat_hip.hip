@@ -97,18 +97,20 @@ static int qcat_opt_index(const char* name) {
 extern "C" int qcat_option_count(void) { return QO_COUNT; }
 extern "C" const char* qcat_option_name(int i) { return i >= 0 && i < QO_COUNT ? g_qcat_opt_name[i] : nullptr; }
 extern "C" const char* qcat_option_doc(int i) { return i >= 0 && i < QO_COUNT ? g_qcat_opt_doc[i] : nullptr; }
-extern "C" void qcat_reset_options(void) { qcat_options_from_env(); }
+extern "C" void qcat_reset_options(void) { qcat_options_from_env(); qk::g_alloc_gen.fetch_add(1); }
 extern "C" int qcat_set_option(const char* name, int64_t value) {
     const int i = qcat_opt_index(name);
     if (i < 0) return set_err(QCAT_ERR_ARG, std::string("qcat_set_option: no option named ") + (name ? name : "(null)"));
     if (value == QOPT_UNSET) return set_err(QCAT_ERR_ARG, "qcat_set_option: the value INT64_MIN means unset (qcat_clear_option)");
     g_qcat_opt[i].store(value, std::memory_order_relaxed);
+    qk::g_alloc_gen.fetch_add(1);                   // (a captured graph holds the launches the old switches chose: dropped, like after a reallocation)
     return 0;
 }
 extern "C" int qcat_clear_option(const char* name) {
     const int i = qcat_opt_index(name);
     if (i < 0) return set_err(QCAT_ERR_ARG, std::string("qcat_clear_option: no option named ") + (name ? name : "(null)"));
     g_qcat_opt[i].store(QOPT_UNSET, std::memory_order_relaxed);
+    qk::g_alloc_gen.fetch_add(1);
     return 0;
 }
 extern "C" int qcat_get_option(const char* name, int64_t* value) {          // returns 1 when the option is set (*value), 0 when it is not
@@ -893,18 +895,21 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
     bool use_packed = packed_kit;
     // a handful of read ends (detect_barcode on one read, a few reads of a test): one wave per alignment, kernels_tiny.inc
     // (QCAT_HIP_TINY_MAX_ENDS: the largest batch that goes there, 0: none; QCAT_HIP_NO_TINY=1)
+    // the path pays while its waves -- one per (read end, template) plus one per (read end, set, barcode) -- fit the chip a few
+    // times over: up to TINY_MAX_WAVES of them (tools/tiny_crossover.py: PBC096 wins to ~180 reads, NBD104 to ~700)
     const QOptVal tiny_env = qopt_get(QO_TINY_MAX_ENDS);
-    const uint64_t tiny_max = opt_on(QO_NO_TINY) ? 0 : (tiny_env ? (uint64_t)std::max<long long>(0, atoll(tiny_env)) : (uint64_t)TINY_MAX_ENDS_DEFAULT);
-    const bool tiny = n_ends > 0 && n_ends <= std::min<uint64_t>(tiny_max, 4096) && hk.mode != QCAT_MODE_SIMPLE && resume_kit_mask < 0 &&
+    int tiny_maxb = 1;
+    for (int t = 0; t < hk.nt; ++t) for (int s2 = 0; s2 < 2; ++s2) tiny_maxb = std::max(tiny_maxb, (int)hk.tpl[t].sets[s2].n);
+    const uint64_t tiny_waves = n_ends * (uint64_t)(hk.nt + tiny_maxb * (hk.mode == QCAT_MODE_DUAL ? 2 : 1));
+    const bool tiny_fits = tiny_env ? n_ends <= (uint64_t)std::max<long long>(0, atoll(tiny_env)) : tiny_waves <= (uint64_t)TINY_MAX_WAVES;
+    const bool tiny = n_ends > 0 && n_ends <= 4096 && tiny_fits && !opt_on(QO_NO_TINY) && hk.mode != QCAT_MODE_SIMPLE && resume_kit_mask < 0 &&
                       !adapter_only && !c->force_generic && hk.gap_open == hk.gap_extend;
     c->last_tiny_ends = tiny ? (uint32_t)n_ends : 0;
-    int tiny_maxb = 1;
     if (tiny) {
-        for (int t = 0; t < hk.nt; ++t) for (int s2 = 0; s2 < 2; ++s2) tiny_maxb = std::max(tiny_maxb, (int)hk.tpl[t].sets[s2].n);
         const size_t need = (size_t)n_ends * 2 * (size_t)tiny_maxb;
         if (need > c->cap_tiny || !c->tiny_tpl) {
             (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc); c->tiny_tpl = nullptr; c->tiny_sc = nullptr; c->cap_tiny = 0;
-            const size_t cap = std::max<size_t>(need, (size_t)TINY_MAX_ENDS_DEFAULT * 2 * 96);
+            const size_t cap = std::max<size_t>(need, (size_t)TINY_MAX_WAVES * 2);
             HIPCHK(q_malloc((void**)&c->tiny_sc, cap * sizeof(int16_t)));
             HIPCHK(q_malloc((void**)&c->tiny_tpl, std::max<size_t>((size_t)n_ends, 4096) * MAX_T * 2 * sizeof(int32_t)));
             c->cap_tiny = cap;

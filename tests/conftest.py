@@ -106,3 +106,25 @@ def hip_options():
     yield set_
     for name, value in saved.items():
         native.set_option(name, value)
+
+
+# ---- which kernels a small batch runs on ------------------------------------------------------------------------------------------
+# Batches of up to 20000 alignments (a few hundred reads) take the one-wave-per-alignment kernels (csrc/kernels_tiny.inc, round 5).
+# The GPU modules below were written to pin the THROUGHPUT kernels -- binary16, bit-sliced, table, general -- on golden cases
+# and seeded batches of exactly such sizes; they keep doing that (QCAT_HIP_NO_TINY for the test), and tests/test_tiny_gpu.py
+# runs the same golden cases and seeded batches on the other path.  Modules that test the product's default behaviour end to
+# end (the scanner API, the driver, the file loop, the one-wave kernels themselves) are left alone.
+_DEFAULT_PATH_MODULES = {"test_tiny_gpu", "test_scan_api_gpu", "test_cli_gpu", "test_stream_gpu", "test_fastq_native", "test_comm_gpu",
+                         "test_synth", "test_sg_align_gpu"}
+
+
+@pytest.fixture(autouse=True)
+def _throughput_kernels_for_small_batches(request):
+    if "gpu" not in request.keywords or request.module.__name__ in _DEFAULT_PATH_MODULES:
+        yield
+        return
+    from qcat_amd import native
+    before = native.get_option("NO_TINY")
+    native.set_option("NO_TINY", 1)
+    yield
+    native.set_option("NO_TINY", before)

@@ -78,7 +78,7 @@ def test_small_batches_against_the_oracle_and_the_throughput_kernels(mode, kit, 
     det = helpers.make_scanner(mode, kit)
     reads = synth.synth_batch(n, 991 + 13 * n, det.layouts, t5, t3, error_rate=e)
     d, recs, traces, rows, cnt, tiny = scan(det, reads)
-    assert tiny == 2 * n                                  # the default: batches of up to 64 read ends
+    assert tiny == 2 * n                                  # the default: batches of up to 20000 alignments
     same_as_oracle(d, reads, recs, traces, rows, cnt)
     monkeypatch.setenv("QCAT_HIP_NO_TINY", "1")
     d2, recs2, traces2, rows2, cnt2, tiny2 = scan(det, reads)
@@ -121,10 +121,13 @@ def test_affine_gaps_and_the_boundary_of_the_path(monkeypatch):
     d, recs, traces, rows, cnt, tiny = scan(det, reads, cfg=cfg2)
     assert tiny == 10
     same_as_oracle(d, reads, recs, traces, rows, cnt)
-    reads = synth.synth_batch(33, 43, det.layouts, 1, 0, error_rate=0.1)
-    d, recs, traces, rows, cnt, tiny = scan(det, reads)
-    assert tiny == 0                                      # 66 read ends
-    same_as_oracle(d, reads, recs, traces, rows, cnt)
+    # the default limit counts alignments (waves): 20000 -- a PBC096 read end is 2 templates + 96 barcodes
+    det96 = scanner.factory(kit="PBC096")
+    for n, on in ((100, True), (103, False)):
+        reads96 = synth.synth_batch(n, 43 + n, det96.layouts, 1, 0, error_rate=0.1)
+        d, recs, traces, rows, cnt, tiny = scan(det96, reads96)
+        assert tiny == (2 * n if on else 0)
+        same_as_oracle(d, reads96, recs, traces, rows, cnt)
     # --detect-middle: a read joined to itself carries its adapter in the interior -> 997; the ends on the tiny kernels first
     det_m = scanner.factory(kit="NBD103/NBD104", scan_middle_adapter=True)
     pair = [reads[0] + reads[0], reads[1]]
