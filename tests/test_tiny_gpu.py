@@ -146,3 +146,32 @@ def test_single_read_calls_through_the_scanner_api():
     for r, want in zip(reads, batch):
         got = det.detect_barcode(r)
         assert got == want
+
+
+def test_custom_kits_and_one_end_only(tmp_path):
+    """Custom kits (flanks of other lengths, barcodes of 24 and 28 letters, a template with N and X) and a 5'-only kit on the
+    one-wave kernels: the kernels hold no letters and no shapes, so nothing is compiled for a kit -- any kit a YAML file
+    describes runs on them as it is."""
+    import random
+
+    import custom_kits
+    rng = random.Random(5)
+    folder = str(tmp_path)
+    shapes = {"T0": ("GGTGCTG", "TTAACCTTTCTGTTGG", 3, 28), "T1": ("GGTCA", "CAG", 11, 24), "T2": ("TG", "CAGCAC", 11, 24),
+              "T3": ("GCTGNNA", "TTAACCTACT", 11, 24)}
+    for name, (up, dn, ctx_len, blen) in shapes.items():
+        custom_kits.write_kit(folder, name, name, up + "N" * blen + dn, custom_kits.random_barcodes(rng, 20, length=blen))
+    for name, (up, dn, ctx_len, blen) in shapes.items():
+        det = scanner.factory(kit=name, kit_folder=folder)
+        cfg = config.qcatConfig()
+        cfg.barcode_context_length = ctx_len
+        for ends in (native.ENDS_5P, native.ENDS_BOTH):
+            d = det.descriptor(qcat_config=cfg, ends=ends)
+            kit = native.NativeKit(d)
+            reads = synth.synth_batch(40, 77, det.layouts, 0, -1, error_rate=0.1) + ["", "ACGT" * 50, "N" * 170]
+            bases, offsets = native.pack_reads(reads)
+            cnt = np.zeros(d.n_count_buckets, dtype=np.int64)
+            recs, traces, rows = ctx().scan(kit, bases, offsets, counts=cnt, trace=True, rows=True)
+            n_ends = len(reads) * (1 if ends == native.ENDS_5P else 2)
+            assert native.HipLibrary.get().lib.qcat_ctx_tiny_ends(ctx().handle) == n_ends
+            same_as_oracle(d, reads, recs, traces, rows, cnt)
