@@ -149,7 +149,7 @@ def test_single_read_calls_through_the_scanner_api():
 
 
 def test_custom_kits_and_one_end_only(tmp_path):
-    """Custom kits (flanks of other lengths, barcodes of 24 and 28 letters, a template with N and X) and a 5'-only kit on the
+    """Custom kits (flanks of other lengths, barcodes of 24 and 28 letters, a template of 92 letters) and a 5'-only kit on the
     one-wave kernels: the kernels hold no letters and no shapes, so nothing is compiled for a kit -- any kit a YAML file
     describes runs on them as it is."""
     import random
@@ -158,7 +158,7 @@ def test_custom_kits_and_one_end_only(tmp_path):
     rng = random.Random(5)
     folder = str(tmp_path)
     shapes = {"T0": ("GGTGCTG", "TTAACCTTTCTGTTGG", 3, 28), "T1": ("GGTCA", "CAG", 11, 24), "T2": ("TG", "CAGCAC", 11, 24),
-              "T3": ("GCTGNNA", "TTAACCTACT", 11, 24)}
+              "T3": ("ATCGCCTACCGTGACAAGAAAGTTGTCGGTGTCTTTGTG", "TTAACCTACTTGCCTGTCGCTCTATCTTC", 11, 24)}       # (92 columns: two per lane)
     for name, (up, dn, ctx_len, blen) in shapes.items():
         custom_kits.write_kit(folder, name, name, up + "N" * blen + dn, custom_kits.random_barcodes(rng, 20, length=blen))
     for name, (up, dn, ctx_len, blen) in shapes.items():
