@@ -516,7 +516,7 @@ struct qcat_ctx {
         uint64_t replays = 0;
     } api_graph, scan_graph;                       // kit-auto calls (scan_batch_auto_impl); calls with a named kit (qcat_scan_batch, round 5)
     // the handful-of-reads path (kernels_tiny.inc): per read end the templates' (raw, end) and the barcodes' raw scores
-    int32_t* tiny_tpl = nullptr; int16_t* tiny_sc = nullptr; size_t cap_tiny = 0; uint32_t tiny_stride = 0;
+    int32_t* tiny_tpl = nullptr; int16_t* tiny_sc = nullptr; size_t cap_tiny = 0, cap_tiny_ends = 0;
     uint32_t last_tiny_ends = 0;                   // read ends the last scan put on that path (0: another path)
     // debug buffers
     int32_t* dbg_tpl = nullptr; size_t cap_dbg_tpl = 0;
@@ -850,6 +850,19 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
     return 0;
 }
 
+// scratch of the one-wave-per-alignment kernels (kernels_tiny.inc) for `n_ends` queries of a kit whose largest set has `maxb` barcodes
+static int tiny_buffers(qcat_ctx* c, size_t n_ends, int maxb) {
+    const size_t need = n_ends * 2 * (size_t)maxb;
+    if (need > c->cap_tiny || n_ends > c->cap_tiny_ends || !c->tiny_tpl) {
+        (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc); c->tiny_tpl = nullptr; c->tiny_sc = nullptr; c->cap_tiny = 0; c->cap_tiny_ends = 0;
+        const size_t cap = std::max<size_t>(need, (size_t)TINY_MAX_WAVES * 2), cap_ends = std::max<size_t>(n_ends, 4096);
+        HIPCHK(q_malloc((void**)&c->tiny_sc, cap * sizeof(int16_t)));
+        HIPCHK(q_malloc((void**)&c->tiny_tpl, cap_ends * MAX_T * 2 * sizeof(int32_t)));
+        c->cap_tiny = cap; c->cap_tiny_ends = cap_ends;
+    }
+    return 0;
+}
+
 // core: scan a resident batch.  dbg: optional debug buffers sized by the caller.
 static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, bool debug, uint32_t row_stride,
                               bool adapter_only = false, int resume_kit_mask = -1, bool keep_counts = false) {
@@ -906,14 +919,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
                       !adapter_only && !c->force_generic && hk.gap_open == hk.gap_extend;
     c->last_tiny_ends = tiny ? (uint32_t)n_ends : 0;
     if (tiny) {
-        const size_t need = (size_t)n_ends * 2 * (size_t)tiny_maxb;
-        if (need > c->cap_tiny || !c->tiny_tpl) {
-            (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc); c->tiny_tpl = nullptr; c->tiny_sc = nullptr; c->cap_tiny = 0;
-            const size_t cap = std::max<size_t>(need, (size_t)TINY_MAX_WAVES * 2);
-            HIPCHK(q_malloc((void**)&c->tiny_sc, cap * sizeof(int16_t)));
-            HIPCHK(q_malloc((void**)&c->tiny_tpl, std::max<size_t>((size_t)n_ends, 4096) * MAX_T * 2 * sizeof(int32_t)));
-            c->cap_tiny = cap;
-        }
+        if ((rc = tiny_buffers(c, (size_t)n_ends, tiny_maxb))) return rc;
         use_packed = false;                        // (no job tables, no lazy windows: the tiny kernels read byte windows)
     }
     g_fill_defer = n != 0 && !opt_on(QO_NO_FILL_MERGE);
@@ -995,7 +1001,7 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
                          [&](const char* nm) { mark(c, nm); }, adapter_only, resume_kit_mask);
         if (rc) return set_err(rc, packed_last_error());
     } else if (tiny) {
-        TinyArgs ta{kp, c->win, c->wlen, (uint32_t)n_ends, c->recs, c->tiny_tpl, c->tiny_sc, (uint32_t)tiny_maxb,
+        TinyArgs ta{kp, c->win, c->wlen, nullptr, nullptr, (uint32_t)n_ends, c->recs, c->tiny_tpl, c->tiny_sc, (uint32_t)tiny_maxb,
                     debug ? c->dbg_tpl : nullptr, (debug && row_stride) ? c->dbg_rows : nullptr, row_stride, 0};
         hipLaunchKernelGGL(k_tiny_adapter, dim3((uint32_t)n_ends * (uint32_t)hk.nt), dim3(64), 0, c->stream, ta);
         hipLaunchKernelGGL(k_tiny_decide, dim3((uint32_t)((n_ends + 63) / 64)), dim3(64), 0, c->stream, ta);
@@ -1919,8 +1925,29 @@ extern "C" int qcat_scan_sequences(qcat_ctx* c, const qcat_kit* ckit, const uint
     if (!rc) rc = grow(&c->results, &c->cap_reads, (size_t)n_seqs);
     if (!rc && n_seqs) {
         KitPtrs kp{kd->kit, kd->codes, kd->ids, kd->tables};
+        const DevKit& hk = kit->hk.dk;
+        // one wave per alignment along its anti-diagonals (kernels_tiny.inc; round 5): L + M steps per alignment and every
+        // template and barcode of a sequence side by side, where the general kernel walks L x M cells of everything on one
+        // lane -- linear gaps and the adapter modes; QCAT_HIP_NO_TINY=1 / simple mode / affine gaps: the general kernel
+        int maxb = 1;
+        for (int t = 0; t < hk.nt; ++t) for (int s2 = 0; s2 < 2; ++s2) maxb = std::max(maxb, (int)hk.tpl[t].sets[s2].n);
+        const bool waves = hk.mode != QCAT_MODE_SIMPLE && hk.gap_open == hk.gap_extend && !opt_on(QO_NO_TINY) && !c->force_generic &&
+                           (uint64_t)n_seqs * 2 <= 65535 && (uint64_t)n_seqs * (uint64_t)hk.nt < (1ull << 31);
+        if (waves) {
+            rc = grow(&c->recs, &c->cap_recs, (size_t)n_seqs);
+            if (!rc) rc = tiny_buffers(c, (size_t)n_seqs, maxb);
+            if (!rc) {
+                TinyArgs ta{kp, nullptr, nullptr, b->bases, b->offsets, n_seqs, c->recs, c->tiny_tpl, c->tiny_sc, (uint32_t)maxb, nullptr, nullptr, 0, 0};
+                hipLaunchKernelGGL(k_tiny_adapter, dim3(n_seqs * (uint32_t)hk.nt), dim3(64), 0, c->stream, ta);
+                hipLaunchKernelGGL(k_tiny_decide, dim3((n_seqs + 63) / 64), dim3(64), 0, c->stream, ta);
+                hipLaunchKernelGGL(k_tiny_barcode, dim3((uint32_t)maxb, n_seqs * 2), dim3(64), 0, c->stream, ta);
+                hipLaunchKernelGGL(k_tiny_select, dim3(n_seqs * 2), dim3(64), 0, c->stream, ta);
+                hipLaunchKernelGGL(k_tiny_store_sequences, dim3((n_seqs + 63) / 64), dim3(64), 0, c->stream, ta, c->results);
+            }
+        } else
         hipLaunchKernelGGL(k_scan_sequences, dim3((n_seqs + GEN_THREADS - 1) / GEN_THREADS), dim3(GEN_THREADS), 0, c->stream,
                            kp, b->bases, b->offsets, n_seqs, c->results);
+        c->last_tiny_ends = (waves && !rc) ? n_seqs : 0;
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(out, c->results, (size_t)n_seqs * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -52,9 +52,21 @@ def test_scan_sequences_vs_oracle(mode, kit, t5, t3):
     d = det.descriptor(ends=native.ENDS_5P)
     kit_h = native.NativeKit(d)
     bases, offsets = native.pack_reads(seqs)
-    got = native.NativeContext(0).scan_sequences(kit_h, bases, offsets)
+    seqs.append(reads[0] * 7)                                # a few thousand letters: many blocks of 64 rows
+    bases, offsets = native.pack_reads(seqs)
+    ctx = native.NativeContext(0)
+    got = ctx.scan_sequences(kit_h, bases, offsets)
+    lib = native.HipLibrary.get().lib
+    assert lib.qcat_ctx_tiny_ends(ctx.handle) == len(seqs)   # one wave per alignment (kernels_tiny.inc, round 5) ...
     want = oracle_lib.scan_sequences(d, seqs)
     assert got.tobytes() == want.tobytes()
+    native.set_option("NO_TINY", 1)                          # ... and the general kernel, one lane per sequence
+    try:
+        general = ctx.scan_sequences(kit_h, bases, offsets)
+        assert lib.qcat_ctx_tiny_ends(ctx.handle) == 0
+    finally:
+        native.set_option("NO_TINY", None)
+    assert general.tobytes() == want.tobytes()
     # windows up to max_align_length: the same records as the fast-kernel path (scan() of a 5' window)
     short = [s for s in seqs if len(s) <= 150]
     if short:
