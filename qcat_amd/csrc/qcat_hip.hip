@@ -1931,18 +1931,20 @@ extern "C" int qcat_scan_sequences(qcat_ctx* c, const qcat_kit* ckit, const uint
         // lane -- linear gaps and the adapter modes; QCAT_HIP_NO_TINY=1 / simple mode / affine gaps: the general kernel
         int maxb = 1;
         for (int t = 0; t < hk.nt; ++t) for (int s2 = 0; s2 < 2; ++s2) maxb = std::max(maxb, (int)hk.tpl[t].sets[s2].n);
-        const bool waves = hk.mode != QCAT_MODE_SIMPLE && hk.gap_open == hk.gap_extend && !opt_on(QO_NO_TINY) && !c->force_generic &&
-                           (uint64_t)n_seqs * 2 <= 65535 && (uint64_t)n_seqs * (uint64_t)hk.nt < (1ull << 31);
+        const bool waves = hk.mode != QCAT_MODE_SIMPLE && hk.gap_open == hk.gap_extend && !opt_on(QO_NO_TINY) && !c->force_generic;
         if (waves) {
-            rc = grow(&c->recs, &c->cap_recs, (size_t)n_seqs);
-            if (!rc) rc = tiny_buffers(c, (size_t)n_seqs, maxb);
-            if (!rc) {
-                TinyArgs ta{kp, nullptr, nullptr, b->bases, b->offsets, n_seqs, c->recs, c->tiny_tpl, c->tiny_sc, (uint32_t)maxb, nullptr, nullptr, 0, 0};
-                hipLaunchKernelGGL(k_tiny_adapter, dim3(n_seqs * (uint32_t)hk.nt), dim3(64), 0, c->stream, ta);
-                hipLaunchKernelGGL(k_tiny_decide, dim3((n_seqs + 63) / 64), dim3(64), 0, c->stream, ta);
-                hipLaunchKernelGGL(k_tiny_barcode, dim3((uint32_t)maxb, n_seqs * 2), dim3(64), 0, c->stream, ta);
-                hipLaunchKernelGGL(k_tiny_select, dim3(n_seqs * 2), dim3(64), 0, c->stream, ta);
-                hipLaunchKernelGGL(k_tiny_store_sequences, dim3((n_seqs + 63) / 64), dim3(64), 0, c->stream, ta, c->results);
+            constexpr uint32_t PIECE = 32767;          // (the barcode kernel's grid has (sequence, set) in y: 65535 at most)
+            const uint32_t piece = std::min(n_seqs, PIECE);
+            rc = grow(&c->recs, &c->cap_recs, (size_t)piece);
+            if (!rc) rc = tiny_buffers(c, (size_t)piece, maxb);
+            for (uint32_t s0 = 0; !rc && s0 < n_seqs; s0 += PIECE) {
+                const uint32_t ns = std::min(PIECE, n_seqs - s0);
+                TinyArgs ta{kp, nullptr, nullptr, b->bases, b->offsets + s0, ns, c->recs, c->tiny_tpl, c->tiny_sc, (uint32_t)maxb, nullptr, nullptr, 0, 0};
+                hipLaunchKernelGGL(k_tiny_adapter, dim3(ns * (uint32_t)hk.nt), dim3(64), 0, c->stream, ta);
+                hipLaunchKernelGGL(k_tiny_decide, dim3((ns + 63) / 64), dim3(64), 0, c->stream, ta);
+                hipLaunchKernelGGL(k_tiny_barcode, dim3((uint32_t)maxb, ns * 2), dim3(64), 0, c->stream, ta);
+                hipLaunchKernelGGL(k_tiny_select, dim3(ns * 2), dim3(64), 0, c->stream, ta);
+                hipLaunchKernelGGL(k_tiny_store_sequences, dim3((ns + 63) / 64), dim3(64), 0, c->stream, ta, c->results + s0);
             }
         } else
         hipLaunchKernelGGL(k_scan_sequences, dim3((n_seqs + GEN_THREADS - 1) / GEN_THREADS), dim3(GEN_THREADS), 0, c->stream,

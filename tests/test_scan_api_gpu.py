@@ -113,3 +113,19 @@ def test_single_read_calls_of_one_shape_replay_a_captured_graph(mode, kit, monke
     for i in (3, 4, 5):
         assert ctx.scan(kit_h, *native.pack_reads([reads[i]])).tobytes() == want[i:i + 1].tobytes()
     assert lib.qcat_ctx_graph_replays(ctx.handle) == off
+
+
+def test_scan_sequences_in_pieces_of_32767():
+    """More sequences than one launch of the one-wave kernels takes ((sequence, set) is a grid dimension): pieces, same records."""
+    det = scanner.factory(kit="NBD103/NBD104")
+    reads = synth.synth_batch(500, 11, det.layouts, 1, 0, error_rate=0.1)
+    distinct = [r[:90 + i % 120] for i, r in enumerate(reads)]
+    d = det.descriptor(ends=native.ENDS_5P)
+    want = oracle_lib.scan_sequences(d, distinct)
+    n = 2 * 32767 + 1234
+    seqs = [distinct[i % 500] for i in range(n)]
+    bases, offsets = native.pack_reads(seqs)
+    ctx = native.NativeContext(0)
+    got = ctx.scan_sequences(native.NativeKit(d), bases, offsets)
+    assert native.HipLibrary.get().lib.qcat_ctx_tiny_ends(ctx.handle) == n
+    assert got.tobytes() == np.concatenate([want] * (n // 500 + 1))[:n].tobytes()

@@ -27,7 +27,7 @@ for n in (1, 4, 16, 32, 64, 128, 256, 512, 1024, 2048):
 
 # ---- qcat_scan_sequences (scan() of whole sequences): the same kernels against the general kernel (one lane per sequence)
 print("scan() of whole sequences (read interiors, ~460 letters):")
-for n in (1, 16, 256, 4096, 30000):
+for n in (1, 16, 256, 4096, 30000, 100000):
     reads = synth.synth_batch(min(n, 2000), 6, det.layouts, 1, 0, error_rate=0.08)
     seqs = [r[150:-150] for r in reads]
     seqs = (seqs * (n // len(seqs) + 1))[:n]
