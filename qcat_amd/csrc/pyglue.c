@@ -47,6 +47,18 @@ static PyObject *k_barcode, *k_score, *k_adapter, *k_end, *k_t5, *k_t3, *k_exit;
 static PyObject* dict_template;          /* the seven keys in the reference's order, values None: a result dict starts as a copy (public API,
                                           one allocation of the right size; PyDict_New() grows at the sixth key) */
 
+enum { SCORE_SLOTS = 1024, LONG_SLOTS = 16384 };
+typedef struct { uint32_t key; PyObject* obj; } score_slot;
+static score_slot score_cache[SCORE_SLOTS];
+static PyObject* long_cache[LONG_SLOTS];      /* 0 .. LONG_SLOTS - 1, made on first use */
+static PyObject* cached_long(long v) {
+    if (v < 0 || v >= LONG_SLOTS) return PyLong_FromLong(v);
+    PyObject* o = long_cache[v];
+    if (!o) { o = PyLong_FromLong(v); if (!o) return NULL; long_cache[v] = o; }
+    Py_INCREF(o);
+    return o;
+}
+
 static PyObject* records_to_dicts(PyObject* self, PyObject* args) {
     (void)self;
     Py_buffer view;
@@ -79,11 +91,23 @@ static PyObject* records_to_dicts(PyObject* self, PyObject* args) {
         const double den = r[i].score_den > 1 ? (double)r[i].score_den : 1.0;
         const double score = b > 0 ? (double)r[i].raw_score * 100.0 / (1.0 * den) : 0.0;
         PyObject* d = PyDict_Copy(dict_template);
-        PyObject* v_score = PyFloat_FromDouble(score);
-        PyObject* v_end = PyLong_FromLong(r[i].adapter_end);
-        PyObject* v_t5 = PyLong_FromLong(r[i].trim5p);
-        PyObject* v_t3 = PyLong_FromLong(r[i].trim3p);
-        PyObject* v_exit = PyLong_FromLong(r[i].exit_status);
+        /* a score is raw * 100 / den of two small integers: a few dozen distinct floats per kit, kept (a float is immutable);
+           read-length sized integers (trim3p, exit codes) likewise -- CPython itself keeps only -5..256 */
+        PyObject* v_score;
+        if (b <= 0) { v_score = PyFloat_FromDouble(0.0); }      /* (no barcode: 0.0 whatever the record's raw fields hold) */
+        else {
+            const uint32_t key = ((uint32_t)(uint16_t)r[i].raw_score << 16) | (uint16_t)r[i].score_den;
+            score_slot* sl = &score_cache[(key ^ (key >> 11)) & (SCORE_SLOTS - 1)];
+            if (sl->obj && sl->key == key) { v_score = sl->obj; Py_INCREF(v_score); }
+            else {
+                v_score = PyFloat_FromDouble(score);
+                if (v_score) { Py_XDECREF(sl->obj); sl->obj = v_score; sl->key = key; Py_INCREF(v_score); }
+            }
+        }
+        PyObject* v_end = cached_long(r[i].adapter_end);
+        PyObject* v_t5 = cached_long(r[i].trim5p);
+        PyObject* v_t3 = cached_long(r[i].trim3p);
+        PyObject* v_exit = cached_long(r[i].exit_status);
         int bad = !d || !v_score || !v_end || !v_t5 || !v_t3 || !v_exit;
         if (!bad)
             bad = PyDict_SetItem(d, k_barcode, barcode) < 0 || PyDict_SetItem(d, k_score, v_score) < 0 || PyDict_SetItem(d, k_adapter, adapter) < 0 ||
