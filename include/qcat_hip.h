@@ -392,6 +392,10 @@ int qcat_ctx_barcode_bitslice_tiles(qcat_ctx* ctx, uint32_t out[3]);
  * reads -- BarcodeScanner.detect_barcode on one read, qcat/scanner_base.py:521-604); 0: the scan took another path; -1: null
  * context.  Tests and diagnostics. */
 int64_t qcat_ctx_tiny_ends(const qcat_ctx* ctx);
+/* Reads of the context's latest --detect-middle scan (BarcodeScanner.scan_middle inside detect_barcode, qcat/scanner_base.py:479-519,
+ * :593-595) whose interior ran on the one-wave-per-alignment kernels: interiors beyond what the packed interior scan takes (more
+ * than 16 384 letters).  Synchronises the context's stream.  Tests and diagnostics. */
+int64_t qcat_ctx_middle_wave_reads(qcat_ctx* ctx);
 
 /* Diagnostics of the context's latest --detect-middle scan (detect_barcode's interior scan, qcat/scanner_base.py:479-519,
  * :593-595): out[0] = tiles of 2048 interiors whose adapter scan ran in bit-sliced form (csrc/kernels_abs_mid.inc), out[1] =

@@ -518,6 +518,9 @@ struct qcat_ctx {
     // the handful-of-reads path (kernels_tiny.inc): per read end the templates' (raw, end) and the barcodes' raw scores
     int32_t* tiny_tpl = nullptr; int16_t* tiny_sc = nullptr; size_t cap_tiny = 0, cap_tiny_ends = 0;
     uint32_t last_tiny_ends = 0;                   // read ends the last scan put on that path (0: another path)
+    // --detect-middle: the reads the packed interior scan leaves (long interiors) on the same kernels (k_midw_*)
+    uint32_t* midw_list = nullptr; int32_t* midw_tpl = nullptr; EndRec* midw_recs = nullptr; int16_t* midw_sc = nullptr; size_t cap_midw_sc = 0;
+    bool midw_ran = false;
     // debug buffers
     int32_t* dbg_tpl = nullptr; size_t cap_dbg_tpl = 0;
     int16_t* dbg_rows = nullptr; size_t cap_dbg_rows = 0;
@@ -561,6 +564,8 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     if (c->scan_graph.exec) (void)hipGraphExecDestroy(c->scan_graph.exec);
     (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->wspec); (void)hipFree(c->win2); (void)hipFree(c->recs); (void)hipFree(c->results);
     (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows); (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc);
+    (void)hipFree(c->midw_list); (void)hipFree(c->midw_tpl); (void)hipFree(c->midw_recs); (void)hipFree(c->midw_sc);
+    (void)hipFree(c->midw_list); (void)hipFree(c->midw_tpl); (void)hipFree(c->midw_recs); (void)hipFree(c->midw_sc);
     (void)hipFree(c->hb_bases); (void)hipFree(c->hb_offsets); (void)hipFree(c->hb_len); (void)hipFree(c->vote_buf);
     packed_scratch_free(&c->packed);
     if (c->pin_bases) (void)hipHostFree(c->pin_bases);
@@ -1034,6 +1039,34 @@ static int scan_resident_impl(qcat_ctx* c, qcat_kit* kit, const qcat_batch* b, b
                 only = c->mid_generic;                  // interiors beyond the packed path's length classes
                 mark(c, "k_middle_packed");
             }
+            // the reads the packed interior scan left (interiors of more than 16 384 letters ...): on one wave per alignment
+            // (kernels_tiny.inc: k_midw_*) up to MIDW_CAP of them per batch, the general kernel takes what is left after that
+            c->midw_ran = false;
+            if (only && hk.gap_open == hk.gap_extend && !opt_on(QO_NO_TINY) && !c->force_generic) {
+                constexpr uint32_t MIDW_CAP = 2048;
+                int maxb = 1;
+                for (int t = 0; t < hk.nt; ++t) for (int s2 = 0; s2 < 2; ++s2) maxb = std::max(maxb, (int)hk.tpl[t].sets[s2].n);
+                if (!c->midw_list) {
+                    HIPCHK(q_malloc((void**)&c->midw_list, (MIDW_CAP + 1) * sizeof(uint32_t)));
+                    HIPCHK(q_malloc((void**)&c->midw_tpl, (size_t)MIDW_CAP * 2 * MAX_T * 2 * sizeof(int32_t)));
+                    HIPCHK(q_malloc((void**)&c->midw_recs, (size_t)MIDW_CAP * 2 * sizeof(EndRec)));
+                }
+                if ((size_t)maxb > c->cap_midw_sc) {
+                    (void)hipFree(c->midw_sc); c->midw_sc = nullptr; c->cap_midw_sc = 0;
+                    HIPCHK(q_malloc((void**)&c->midw_sc, (size_t)MIDW_CAP * 2 * 2 * (size_t)maxb * sizeof(int16_t)));
+                    c->cap_midw_sc = (size_t)maxb;
+                }
+                uint32_t* count = c->midw_list + MIDW_CAP;
+                HIPCHK(hipMemsetAsync(count, 0, sizeof(uint32_t), c->stream));
+                MidWaveArgs ma{kp, b->bases, b->offsets, n, c->results, c->mid_generic, c->midw_list, count, MIDW_CAP,
+                               c->midw_tpl, c->midw_recs, c->midw_sc, (uint32_t)maxb};
+                hipLaunchKernelGGL(k_midw_list, dim3((n + 255) / 256), dim3(256), 0, c->stream, ma);
+                hipLaunchKernelGGL(k_midw_adapter, dim3(1024), dim3(64), 0, c->stream, ma);
+                hipLaunchKernelGGL(k_midw_decide, dim3(MIDW_CAP * 2 / 64), dim3(64), 0, c->stream, ma);
+                hipLaunchKernelGGL(k_midw_barcode, dim3(4096), dim3(64), 0, c->stream, ma);
+                hipLaunchKernelGGL(k_midw_finish, dim3(MIDW_CAP / 64), dim3(64), 0, c->stream, ma);
+                c->midw_ran = true;
+            }
             hipLaunchKernelGGL(k_scan_middle, dim3((n + GEN_THREADS - 1) / GEN_THREADS), dim3(GEN_THREADS), 0, c->stream,
                                kp, b->bases, b->offsets, n, c->results, only);
             hipLaunchKernelGGL(k_count, dim3(blocks), dim3(256), 0, c->stream, kp, c->results, b->offsets, b->true_len, n, c->counts);
@@ -1075,6 +1108,16 @@ extern "C" int qcat_ctx_fetch_counts(qcat_ctx* c, int64_t* counts, int32_t n_buc
 
 extern "C" void* qcat_ctx_stream(qcat_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int64_t qcat_ctx_tiny_ends(const qcat_ctx* c) { return c ? (int64_t)c->last_tiny_ends : -1; }
+// reads whose interior the latest --detect-middle scan put on the one-wave kernels (k_midw_*: interiors the packed interior scan
+// does not take); synchronises the stream; -1: null context, 0: none / the path did not run
+extern "C" int64_t qcat_ctx_middle_wave_reads(qcat_ctx* c) {
+    if (!c) return -1;
+    if (!c->midw_ran || !c->midw_list) return 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    uint32_t cnt = 0;
+    if (hipMemcpy(&cnt, c->midw_list + 2048, sizeof cnt, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)std::min<uint32_t>(cnt, 2048u);
+}
 extern "C" int64_t qcat_ctx_graph_replays(const qcat_ctx* c) { return c ? (int64_t)(c->api_graph.replays + c->scan_graph.replays) : -1; }
 // diagnostics of the latest scan of the read ends: super-tiles (2048 barcode alignments each) its bit-sliced barcode kernels took, per
 // hot class summed over the (template, set) groups -- out[0] regions a few bases short of nominal (front-padded units), out[1]

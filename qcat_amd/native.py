@@ -311,6 +311,7 @@ class HipLibrary(object):
             "qcat_ctx_graph_replays": (C.c_int64, [vp]),
             "qcat_ctx_barcode_bitslice_tiles": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
             "qcat_ctx_tiny_ends": (C.c_int64, [vp]),
+            "qcat_ctx_middle_wave_reads": (C.c_int64, [vp]),
             "qcat_ctx_middle_bitslice_tiles": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
             "qcat_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
             "qcat_ctx_destroy": (None, [vp]),

@@ -175,3 +175,39 @@ def test_custom_kits_and_one_end_only(tmp_path):
             n_ends = len(reads) * (1 if ends == native.ENDS_5P else 2)
             assert native.HipLibrary.get().lib.qcat_ctx_tiny_ends(ctx().handle) == n_ends
             same_as_oracle(d, reads, recs, traces, rows, cnt)
+
+
+def test_detect_middle_on_long_reads(monkeypatch):
+    """--detect-middle (scanner_base.py:479-519) on reads whose interior is beyond the packed interior scan (more than 16 384
+    letters): the one-wave kernels take them (k_midw_*), the general kernel does when they are switched off -- same records as
+    the oracle either way; reads of ordinary length in the same batch stay on the packed interior scan."""
+    import random
+
+    from qcat_amd import utils
+    rng = random.Random(77)
+    det = scanner.factory(kit="NBD103/NBD104", scan_middle_adapter=True)
+    base = synth.synth_batch(12, 5, det.layouts, 1, 0, error_rate=0.06)
+
+    def rnd(n):
+        return "".join(rng.choice("ACGT") for _ in range(n))
+    reads = []
+    for i, r in enumerate(base):
+        kind = i % 4
+        inner = {0: rnd(300), 1: r, 2: utils.revcomp(r), 3: r[:120] + rnd(40)}[kind]     # nothing / the read / its reverse complement / its 5' adapter only
+        reads.append(r[:220] + rnd(9000 + 1500 * i) + inner + rnd(9000) + r[-220:])
+    reads += base[:6] + [base[0] + base[0]]                       # ordinary reads and an ordinary chimera beside them
+    d = det.descriptor(ends=native.ENDS_BOTH, scan_middle=True)
+    kit = native.NativeKit(d)
+    bases, offsets = native.pack_reads(reads)
+    want = oracle_lib.scan(d, reads, threads=8)
+    assert 997 in want["exit_status"][:12] and (want["exit_status"][:12] != 997).any()
+    lib = native.HipLibrary.get().lib
+    monkeypatch.setenv("QCAT_HIP_NO_TINY", "1")                   # (the read ends of this small batch on the throughput kernels either way)
+    got = ctx().scan(kit, bases, offsets)
+    assert lib.qcat_ctx_middle_wave_reads(ctx().handle) == 0
+    assert got.tobytes() == want.tobytes()
+    monkeypatch.delenv("QCAT_HIP_NO_TINY")
+    got = ctx().scan(kit, bases, offsets)
+    called_long = int((oracle_lib.scan(det.descriptor(ends=native.ENDS_BOTH, scan_middle=False), reads[:12])["adapter_idx"] >= 0).sum())
+    assert lib.qcat_ctx_middle_wave_reads(ctx().handle) == called_long > 0
+    assert got.tobytes() == want.tobytes()
