@@ -565,7 +565,6 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     (void)hipFree(c->win); (void)hipFree(c->wlen); (void)hipFree(c->wspec); (void)hipFree(c->win2); (void)hipFree(c->recs); (void)hipFree(c->results);
     (void)hipFree(c->counts); (void)hipFree(c->dbg_tpl); (void)hipFree(c->dbg_rows); (void)hipFree(c->tiny_tpl); (void)hipFree(c->tiny_sc);
     (void)hipFree(c->midw_list); (void)hipFree(c->midw_tpl); (void)hipFree(c->midw_recs); (void)hipFree(c->midw_sc);
-    (void)hipFree(c->midw_list); (void)hipFree(c->midw_tpl); (void)hipFree(c->midw_recs); (void)hipFree(c->midw_sc);
     (void)hipFree(c->hb_bases); (void)hipFree(c->hb_offsets); (void)hipFree(c->hb_len); (void)hipFree(c->vote_buf);
     packed_scratch_free(&c->packed);
     if (c->pin_bases) (void)hipHostFree(c->pin_bases);

@@ -3,7 +3,7 @@
 selections (named kits, kit auto, the dual kit), chimeric reads (the read joined to itself / to its reverse complement), inserts of
 random length so that one big tile of 2048 interiors holds many length classes (front padding of hundreds of rows), N runs and
 lower case inside interiors, reads without an interior; both kernel forms (one wave per tile / the two-wave pipeline), sometimes
-a plane buffer that is too small.  Records and count vector against the CPU oracle, and the tiles that ran bit-sliced are counted
+a plane buffer that is too small; a few reads with interiors beyond the packed path (the one-wave kernels).  Records and count vector against the CPU oracle, and the tiles that ran bit-sliced are counted
 through qcat_ctx_middle_bitslice_tiles.
     python tools/fuzz_middle.py FIRST LAST"""
 import ctypes as C
@@ -50,6 +50,12 @@ for seed in range(first, last):
             reads.append(r[:p] + "N" * rng.randrange(1, 40) + r[p:])
         elif k == 5:
             reads.append(r.lower() if rng.random() < 0.5 else r[:rng.randrange(0, 420)])
+        elif k == 6 and j % 16 == 6:
+            # an interior beyond the packed interior scan's 16 384 letters (the one-wave kernels: k_midw_*), with or without the
+            # read / its reverse complement / a stretch of N inside
+            inner = rng.choice(["", r, "".join(comp.get(ch, "N") for ch in reversed(r)), "N" * 50])
+            filler = "".join(rng.choice("ACGT") for _ in range(rng.randrange(8200, 9500)))
+            reads.append(r[:200] + filler + inner + filler[::-1] + r[-200:])
         else:
             reads.append(r)
     d = det.descriptor()
@@ -67,10 +73,11 @@ for seed in range(first, last):
     tiles = (C.c_uint32 * 4)()
     lib.qcat_ctx_middle_bitslice_tiles(ctx.handle, tiles)
     on_path += tiles[0] > 0
+    long_reads = lib.qcat_ctx_middle_wave_reads(ctx.handle)
     mism = int(np.count_nonzero(got != want))
     ok = mism == 0 and np.array_equal(cnt, want_cnt)
-    print("seed %3d %-6s %-16s t5 %2d t3 %2d n %4d one-wave %s rows %-5s big tiles %d / %d, tiles of 128 left to binary16 %d / %d, 997: %d : %s" % (
-        seed, mode, kit, t5, t3, n, one_wave, rows, tiles[0], tiles[1], tiles[2], tiles[3], int((got["exit_status"] == 997).sum()),
+    print("seed %3d %-6s %-16s t5 %2d t3 %2d n %4d one-wave %s rows %-5s big tiles %d / %d, tiles of 128 left to binary16 %d / %d, long interiors on waves %d, 997: %d : %s" % (
+        seed, mode, kit, t5, t3, n, one_wave, rows, tiles[0], tiles[1], tiles[2], tiles[3], long_reads, int((got["exit_status"] == 997).sum()),
         "ok" if ok else "MISMATCH %d" % mism), flush=True)
     bad += not ok
 print("seeds %d..%d: %d failures, the bit-sliced interior scan ran in %d" % (first, last - 1, bad, on_path))
