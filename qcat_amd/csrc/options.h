@@ -68,6 +68,7 @@
     X(PIPELINE_CHUNK, "reads per chunk of the host pipeline") \
     X(PIPELINE_TRACE, "1: print the split of a pipelined call") \
     X(ABS_SERIAL, "1: the bit-sliced adapter launches of a scan one after the other instead of side by side (A/B)") \
+    X(NO_ZERO_COPY, "1: host-buffer calls of a handful of reads copy their staging to the device like bigger ones (A/B)") \
     X(NO_TINY, "1: batches of a handful of read ends take the throughput kernels like every other batch") \
     X(TINY_MAX_ENDS, "largest batch (read ends, at most 4096) on the one-wave-per-alignment kernels (default: by the number of alignments, 20000)") \
     X(STREAM_SYNC_RELEASE, "1: the file loop's reader gives a written segment's pages back itself (A/B: a thread of its own)") \
