@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QCAT_ABI_VERSION 5
+#define QCAT_ABI_VERSION 6
 
 /* Base code space shared by host and device (qcat_amd/codes.py): parasail's mapper sends the
  * alphabet letters (either case) to their index and everything else to the '*' row
@@ -133,7 +133,26 @@ typedef struct qcat_kit_desc {
      * scanner_base.py:680-689, counts every read). */
     int32_t min_read_length;
     int32_t trim_reads;
+    /* which of the reference's two alignment routines decides an alignment's END POSITION (QCAT_R1_*, below): the
+     * reference binds `parasail.sg_striped_32` when parasail reports SSE2 and plain `parasail.sg` otherwise
+     * (qcat/scanner_base.py:20-26).  Scores never differ; end_query -- and through it adapter_end, the barcode region
+     * and the trims -- can, when the last row's and the last column's maxima tie. */
+    int32_t r1_rule;
 } qcat_kit_desc;
+
+/* Rule R1 -- where a semi-global alignment ENDS when its score is reached on both borders (ABI 6).  Both restate parasail
+ * 2.x as recalled (the library is absent from this image: PARITY UNPINNED beyond the reference's own known answers):
+ *   QCAT_R1_STRIPED  `sg_striped_32`: the last row first (target index ascending, strictly greater replaces), then the last
+ *                    column: a strictly greater cell replaces the result, an equal one only when the result already sits in
+ *                    the last column (then the FIRST row reaching the maximum counts) -- what rounds 1-5 implemented;
+ *   QCAT_R1_SCALAR   `sg`: the last column is looked at while the rows go by (strictly greater replaces: the first row
+ *                    reaching its maximum), then the last row, target index ascending, strictly greater replaces -- on a
+ *                    tie between the two borders the LAST COLUMN wins.
+ * One switch, every implementation: this library's kernels (DevKit::r1_scalar), oracle/qcat_oracle.c (qo_sg_rule, the
+ * descriptor's field), tests/golden/sg_independent.py sg(rule=...). */
+enum { QCAT_R1_STRIPED = 0, QCAT_R1_SCALAR = 1 };
+/* qcat_sg_align: OR into `with_stats` to align under QCAT_R1_SCALAR (the module-level helpers have no kit) */
+#define QCAT_SG_R1_SCALAR 0x100
 
 /* Result record: the dict of qcat/scanner_base.py:381-388 as indices (24 bytes, little endian).
  * barcode_score of the dict == raw_score * 100.0 / score_den (scanner_base.py:119), recomputed

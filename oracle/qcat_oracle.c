@@ -70,8 +70,10 @@ static void qo_init_tables(void) {
  * ---------------------------------------------------------------------------------------- */
 typedef struct qo_align { int32_t score, end_query, end_ref; } qo_align;
 
-void qo_sg_codes(const uint8_t* q, int L, const uint8_t* t, int M, int open, int extend,
-                 const int8_t* mat, qo_align* out) {
+/* rule: QCAT_R1_STRIPED / QCAT_R1_SCALAR (include/qcat_hip.h): which of the reference's two routines
+ * (qcat/scanner_base.py:20-26: parasail.sg_striped_32 with SSE2, plain parasail.sg without) places the end */
+void qo_sg_codes_rule(const uint8_t* q, int L, const uint8_t* t, int M, int open, int extend,
+                      const int8_t* mat, int rule, qo_align* out) {
     int32_t Hrow[QCAT_MAX_TEMPLATE_LEN + 2], Frow[QCAT_MAX_TEMPLATE_LEN + 2];
     int32_t cmax = QO_NEG, cfirst = 0;      /* last-column maximum and the first row reaching it */
     for (int j = 0; j <= M; ++j) { Hrow[j] = 0; Frow[j] = QO_NEG; }
@@ -95,21 +97,44 @@ void qo_sg_codes(const uint8_t* q, int L, const uint8_t* t, int M, int open, int
         }
         if (Hrow[M] > cmax) { cmax = Hrow[M]; cfirst = i; }
     }
-    /* end position: parasail sg_striped rule */
     int32_t score = QO_NEG, end_q = L - 1, end_r = 0;
-    for (int j = 1; j <= M; ++j) {          /* row "query fully consumed", strict > */
-        if (Hrow[j] > score) { score = Hrow[j]; end_r = j - 1; end_q = L - 1; }
-    }
-    if (cmax > score || (cmax == score && end_r == M - 1)) {
+    if (rule == QCAT_R1_SCALAR) {
+        /* plain parasail.sg as recalled: the last column was looked at while the rows went by (strict >: the first row
+         * reaching its maximum -- cmax / cfirst above), then the last row, target index ascending, strict > */
         score = cmax; end_r = M - 1; end_q = cfirst - 1;
+        for (int j = 1; j <= M; ++j) {
+            if (Hrow[j] > score) { score = Hrow[j]; end_r = j - 1; end_q = L - 1; }
+        }
+    } else {
+        /* end position: parasail sg_striped rule */
+        for (int j = 1; j <= M; ++j) {          /* row "query fully consumed", strict > */
+            if (Hrow[j] > score) { score = Hrow[j]; end_r = j - 1; end_q = L - 1; }
+        }
+        if (cmax > score || (cmax == score && end_r == M - 1)) {
+            score = cmax; end_r = M - 1; end_q = cfirst - 1;
+        }
     }
     out->score = score; out->end_query = end_q; out->end_ref = end_r;
 }
+void qo_sg_codes(const uint8_t* q, int L, const uint8_t* t, int M, int open, int extend,
+                 const int8_t* mat, qo_align* out) {
+    qo_sg_codes_rule(q, L, t, M, open, extend, mat, QCAT_R1_STRIPED, out);
+}
 
 /* ASCII front end (used by the parasail stand-in of tests/golden/make_golden.py) */
+int qo_sg_rule(const char* s1, int L, const char* s2, int M, int open, int extend,
+               const int8_t* mat, int rule, int32_t* score, int32_t* end_query, int32_t* end_ref);
 int qo_sg(const char* s1, int L, const char* s2, int M, int open, int extend,
           const int8_t* mat, int32_t* score, int32_t* end_query, int32_t* end_ref) {
+    return qo_sg_rule(s1, L, s2, M, open, extend, mat, QCAT_R1_STRIPED, score, end_query, end_ref);
+}
+int qo_sg_rule(const char* s1, int L, const char* s2, int M, int open, int extend,
+               const int8_t* mat, int rule, int32_t* score, int32_t* end_query, int32_t* end_ref) {
     qo_init_tables();
+    if (rule != QCAT_R1_STRIPED && rule != QCAT_R1_SCALAR) {
+        snprintf(qo_err, sizeof qo_err, "qo_sg: unknown R1 rule %d", rule);
+        return QCAT_ERR_ARG;
+    }
     if (L <= 0 || M <= 0 || L > QO_MAXW || M > QCAT_MAX_TEMPLATE_LEN) {
         snprintf(qo_err, sizeof qo_err, "qo_sg: bad lengths %d x %d", L, M);
         return QCAT_ERR_ARG;
@@ -119,7 +144,7 @@ int qo_sg(const char* s1, int L, const char* s2, int M, int open, int extend,
     for (int i = 0; i < L; ++i) q[i] = qo_code_of[(uint8_t)s1[i]];
     for (int j = 0; j < M; ++j) t[j] = qo_code_of[(uint8_t)s2[j]];
     qo_align a;
-    qo_sg_codes(q, L, t, M, open, extend, mat, &a);
+    qo_sg_codes_rule(q, L, t, M, open, extend, mat, rule, &a);
     free(q);
     *score = a.score; *end_query = a.end_query; *end_ref = a.end_ref;
     return 0;
@@ -141,8 +166,10 @@ int qo_sg(const char* s1, int L, const char* s2, int M, int open, int extend,
  * ---------------------------------------------------------------------------------------- */
 typedef struct qo_stats { int32_t score, end_query, end_ref, matches, length; } qo_stats;
 
-int qo_sg_stats_rule(const char* s1, int L, const char* s2, int M, int open, int extend, const int8_t* mat, int rule, qo_stats* out) {
+int qo_sg_stats_rule(const char* s1, int L, const char* s2, int M, int open, int extend, const int8_t* mat, int rule_and_r1, qo_stats* out) {
     qo_init_tables();
+    const int r1_scalar = (rule_and_r1 & QCAT_SG_R1_SCALAR) != 0;     /* as qcat_sg_align's with_stats: QCAT_STATS_* | QCAT_SG_R1_SCALAR */
+    const int rule = rule_and_r1 & ~QCAT_SG_R1_SCALAR;
     if (rule != QCAT_STATS_PARASAIL6 && rule != QCAT_STATS_PARASAIL5 && rule != QCAT_STATS_ROUND3) {
         snprintf(qo_err, sizeof qo_err, "qo_sg_stats: unknown rule %d", rule);
         return QCAT_ERR_ARG;
@@ -192,7 +219,7 @@ int qo_sg_stats_rule(const char* s1, int L, const char* s2, int M, int open, int
     int32_t score = QO_NEG, end_q = L - 1, end_r = 0, mm = 0, ll = 0;
     for (int j = 1; j <= M; ++j)
         if (H[j] > score) { score = H[j]; end_r = j - 1; end_q = L - 1; mm = HM[j]; ll = HL[j]; }
-    if (cmax > score || (cmax == score && end_r == M - 1)) { score = cmax; end_r = M - 1; end_q = cfirst - 1; mm = cm; ll = cl; }
+    if (cmax > score || (cmax == score && (end_r == M - 1 || r1_scalar))) { score = cmax; end_r = M - 1; end_q = cfirst - 1; mm = cm; ll = cl; }
     out->score = score; out->end_query = end_q; out->end_ref = end_r; out->matches = mm; out->length = ll;
     return 0;
 }
@@ -341,7 +368,7 @@ static qo_best_tpl qo_find_best_template(const qo_kit* k, const uint8_t* w, int 
     for (int t = 0; t < k->nt; ++t) {
         const qo_tpl* p = &k->tpl[t];
         qo_align a;
-        qo_sg_codes(w, L, p->codes, p->len, k->d.gap_open, k->d.gap_extend, k->d.adapter_matrix, &a);
+        qo_sg_codes_rule(w, L, p->codes, p->len, k->d.gap_open, k->d.gap_extend, k->d.adapter_matrix, k->d.r1_rule, &a);
         if (tr) { tr->tpl_raw[t] = a.score; tr->tpl_end[t] = a.end_query; }
         double norm = a.score * 100.0 / (double)p->den;
         if (b.score < norm) { b.score = norm; b.idx = t; b.end = a.end_query; b.raw = a.score; }
@@ -512,7 +539,7 @@ static double qo_scan_seq_score(const qo_kit* k, const uint8_t* w, int L, int ki
         for (int i = 0; i < ns; ++i) {
             const qo_tpl* p = &k->tpl[sub[i]];
             qo_align a;
-            qo_sg_codes(w, L, p->codes, p->len, k->d.gap_open, k->d.gap_extend, k->d.adapter_matrix, &a);
+            qo_sg_codes_rule(w, L, p->codes, p->len, k->d.gap_open, k->d.gap_extend, k->d.adapter_matrix, k->d.r1_rule, &a);
             double norm = a.score * 100.0 / (double)p->den;
             if (b.score < norm) { b.score = norm; b.idx = i; b.end = a.end_query; b.raw = a.score; }
         }

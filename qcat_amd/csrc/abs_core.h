@@ -296,8 +296,11 @@ ABS_FN void abs_lastrow_step(AbsLastRow& r, const u32 (&b)[ABS_NP], bool first) 
 //   new maximum;  col = s_col > s_row || (s_col == s_row && jr == M)  -- and jr == M implies s_row = H(L,M) <= s_col,
 //   so col = newmax | (Fc > Fr);   score = sum - 2M + (col ? Fc : Fr) - 1;   end_query = col ? ic : L - 1.
 // Out: val = sum + (col ? Fc : Fr)  (the caller subtracts 2M + 1 after the planes are un-transposed), endq planes.
-ABS_FN void abs_decide(const AbsBorder& bd, const AbsLastRow& lr, unsigned last_row_index, u32 (&val)[ABS_NF + 1], u32 (&endq)[ABS_NI]) {
-    const u32 col = lr.newmax | abs_gt(bd.Fc, lr.Fr);
+// r1_scalar (wave-uniform; QCAT_R1_SCALAR, plain parasail.sg's order): the last column wins every tie, col = s_col >= s_row
+// = !(Fr > Fc)  (jr == M still implies it).
+ABS_FN void abs_decide(const AbsBorder& bd, const AbsLastRow& lr, unsigned last_row_index, u32 (&val)[ABS_NF + 1], u32 (&endq)[ABS_NI],
+                       bool r1_scalar = false) {
+    const u32 col = r1_scalar ? ~abs_gt(lr.Fr, bd.Fc) : (lr.newmax | abs_gt(bd.Fc, lr.Fr));
     u32 c = 0u;
 #pragma unroll
     for (int k = 0; k < ABS_NF; ++k) {

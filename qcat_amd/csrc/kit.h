@@ -119,10 +119,12 @@ struct DevKit {
     uint16_t adapter_w16[5 * 8];
     int32_t adapter_f16;        // the binary16 adapter DP is exact for this kit (static adapter kernels allowed)
     int32_t adapter_f16_headroom;   // 2047 - (largest value the window-sized biased adapter DP can reach)
+    int32_t r1_scalar;          // rule R1 as plain parasail.sg orders it (include/qcat_hip.h QCAT_R1_SCALAR): on a tie of the two
+                                // borders' maxima the last column wins; 0: sg_striped_32's order
     int32_t abs_ok;             // the adapter scoring is +5 / -2 / N -1 / gap 2 and every template is made of A, T, G, C, N:
                                 // the bit-sliced adapter kernels (kernels_abs.inc) are exact for this kit
     int8_t amat[49], bmat[49];
-    int8_t pad_[2];
+    int8_t pad_[2];             // (sizeof stays a multiple of 4)
     DevTpl tpl[MAX_T];
 };
 

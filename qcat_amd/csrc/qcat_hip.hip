@@ -796,6 +796,7 @@ static int middle_packed(qcat_ctx* c, KitPtrs kp, const DevKit& hk, const qcat_b
             // launches share a SIMD): 4.79 against 4.91 ms per step at 1 M reads (tools/r04_absmid_prio.sh); QCAT_HIP_MIDDLE_ABS_PRIO
             const QOptVal pr = opt_is_set(QO_MIDDLE_ABS_PRIO) ? qopt_get(QO_MIDDLE_ABS_PRIO) : qopt_get(QO_ABS_PRIO);
             am.prio = pr ? atoi(pr) : 2;
+            am.r1_scalar = hk.r1_scalar;
             HIPCHK(packed_fill(am.cursor, 0, MAX_T * 4, st));
             HIPCHK(packed_fill_flush(st));
             // the M-ends' first windows (k_mid_windows) come from the packed batch too: QCAT_HIP_MIDDLE_ABS_WINDOWS=0: from the reads, beside
@@ -2016,12 +2017,13 @@ extern "C" int qcat_scan_sequences(qcat_ctx* c, const qcat_kit* ckit, const uint
 
 extern "C" int qcat_sg_align(qcat_ctx* c, const uint8_t* queries, const uint64_t* q_offsets, const uint8_t* targets,
                              const uint64_t* t_offsets, uint32_t n, int32_t gap_open, int32_t gap_extend, const int8_t* matrix,
-                             int32_t with_stats, qcat_alignment* out) {
+                             int32_t with_stats_and_rule, qcat_alignment* out) {
+    const int32_t r1_flag = with_stats_and_rule & QCAT_SG_R1_SCALAR, with_stats = with_stats_and_rule & ~QCAT_SG_R1_SCALAR;
     if (!c || !q_offsets || !t_offsets || !matrix || !out) return set_err(QCAT_ERR_ARG, "qcat_sg_align: null argument");
     if (n == 0) return 0;
     if (gap_open < 0 || gap_extend < 0) return set_err(QCAT_ERR_ARG, "qcat_sg_align: negative gap cost");
     if (with_stats != QCAT_STATS_NONE && with_stats != QCAT_STATS_PARASAIL6 && with_stats != QCAT_STATS_PARASAIL5 && with_stats != QCAT_STATS_ROUND3)
-        return set_err(QCAT_ERR_ARG, "qcat_sg_align: with_stats must be one of QCAT_STATS_*");
+        return set_err(QCAT_ERR_ARG, "qcat_sg_align: with_stats must be one of QCAT_STATS_* (optionally | QCAT_SG_R1_SCALAR)");
     for (uint32_t i = 0; i < n; ++i) {
         if (q_offsets[i + 1] < q_offsets[i] || t_offsets[i + 1] < t_offsets[i]) return set_err(QCAT_ERR_ARG, "offsets must be non-decreasing");
         if (t_offsets[i + 1] - t_offsets[i] > (uint64_t)MAX_TLEN) return set_err(QCAT_ERR_UNSUPPORTED, "qcat_sg_align: target longer than QCAT_MAX_TEMPLATE_LEN");
@@ -2042,7 +2044,7 @@ extern "C" int qcat_sg_align(qcat_ctx* c, const uint8_t* queries, const uint64_t
     SgMatrix m;
     memcpy(m.m, matrix, 49);
     hipLaunchKernelGGL(k_sg_align, dim3(blocks), dim3(GEN_THREADS), 0, c->stream, dq.as<uint8_t>(), dqo.as<uint64_t>(), dt.as<uint8_t>(),
-                       dto.as<uint64_t>(), n, (int)gap_open, (int)gap_extend, m, (int)with_stats, dscr.as<int32_t>(), dout.as<qcat_alignment>());
+                       dto.as<uint64_t>(), n, (int)gap_open, (int)gap_extend, m, (int)(with_stats | r1_flag), dscr.as<int32_t>(), dout.as<qcat_alignment>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)n * sizeof(qcat_alignment), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -12,7 +12,28 @@ import threading
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
+
+# Rule R1 -- which of the reference's two alignment routines places an alignment's END (include/qcat_hip.h QCAT_R1_*).
+# The reference binds `parasail.sg_striped_32` at import when parasail reports SSE2 and plain `parasail.sg` otherwise
+# (qcat/scanner_base.py:20-26); the equivalent here is this module-level setting, read when a kit descriptor is built:
+# "striped" (default: what every x86 host runs) or "scalar".  QCAT_R1_RULE in the environment sets the default.
+R1_STRIPED, R1_SCALAR = 0, 1
+SG_R1_SCALAR = 0x100            # OR-ed into qcat_sg_align's with_stats
+_R1_NAMES = {"striped": R1_STRIPED, "sg_striped_32": R1_STRIPED, "scalar": R1_SCALAR, "sg": R1_SCALAR}
+_r1_rule = [_R1_NAMES.get(os.environ.get("QCAT_R1_RULE", "striped").lower(), R1_STRIPED)]
+
+
+def set_r1_rule(rule):
+    """'striped' / 'scalar' (or R1_STRIPED / R1_SCALAR): the end-position rule of every kit descriptor built from now on and of
+    the module-level alignment helpers.  Returns the previous rule."""
+    old = _r1_rule[0]
+    _r1_rule[0] = _R1_NAMES[rule.lower()] if isinstance(rule, str) else (R1_SCALAR if int(rule) else R1_STRIPED)
+    return old
+
+
+def get_r1_rule():
+    return _r1_rule[0]
 MODE_EPI2ME, MODE_DUAL, MODE_SIMPLE = 0, 1, 2
 ENDS_5P, ENDS_BOTH = 1, 3
 MAX_TEMPLATES = 16
@@ -45,7 +66,7 @@ class KitDesc(C.Structure):
                 ("region_min_adapter_score", C.c_double),
                 ("n_barcode_slots", C.c_int32), ("n_kit_slots", C.c_int32),
                 ("scan_middle_adapter", C.c_int32), ("middle_min_score", C.c_double),
-                ("min_read_length", C.c_int32), ("trim_reads", C.c_int32)]
+                ("min_read_length", C.c_int32), ("trim_reads", C.c_int32), ("r1_rule", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -106,7 +127,7 @@ class KitDescriptor(object):
     """
 
     def __init__(self, layouts, qcat_config, mode="epi2me", min_quality=None, ends=ENDS_BOTH,
-                 scan_middle=False, min_read_length=0, trim=False):
+                 scan_middle=False, min_read_length=0, trim=False, r1_rule=None):
         if mode not in ("epi2me", "dual", "simple"):
             raise RuntimeError("Invalid demultiplexing mode: {}".format(mode))
         if len(layouts) > MAX_TEMPLATES:
@@ -204,6 +225,7 @@ class KitDescriptor(object):
         # the driver's min-length filter of the count histogram (qcat/cli.py:521-534); 0 = count every read
         d.min_read_length = max(0, int(min_read_length))
         d.trim_reads = 1 if trim else 0
+        d.r1_rule = get_r1_rule() if r1_rule is None else int(r1_rule)
         self.scan_middle = bool(scan_middle)
         self.desc = d
 
@@ -659,7 +681,8 @@ def sg_align(ctx, queries, targets, gap_open, gap_extend, table, with_stats=Fals
     hip = HipLibrary.get()
     hip.check(hip.lib.qcat_sg_align(ctx.handle, qb.ctypes.data, qo.ctypes.data, tb.ctypes.data, to.ctypes.data, n,
                                     int(gap_open), int(gap_extend), t.ctypes.data,
-                                    STATS_PARASAIL6 if with_stats is True else int(with_stats or 0), out.ctypes.data))
+                                    (STATS_PARASAIL6 if with_stats is True else int(with_stats or 0))
+                                    | (SG_R1_SCALAR if get_r1_rule() == R1_SCALAR else 0), out.ctypes.data))
     return out
 
 

@@ -220,7 +220,7 @@ class BarcodeScanner(object):
 
     def _native_kit(self, layouts, qcat_config, ends):
         key = (tuple(id(l) for l in layouts), qcat_config.fingerprint(), ends, self.min_quality,
-               bool(self.scan_middle_adapter))
+               bool(self.scan_middle_adapter), native.get_r1_rule())
         kit = self._kits.get(key)
         if kit is None:
             kit = native.NativeKit(self.descriptor(layouts, qcat_config, ends))

@@ -15,8 +15,13 @@
 #include "abs_core.h"
 #include "abs_generated.inc"
 
-extern "C" int qo_sg(const char* s1, int L, const char* s2, int M, int open, int extend, const int8_t* mat,
-                     int32_t* score, int32_t* end_query, int32_t* end_ref);
+extern "C" int qo_sg_rule(const char* s1, int L, const char* s2, int M, int open, int extend, const int8_t* mat, int rule,
+                          int32_t* score, int32_t* end_query, int32_t* end_ref);
+static int g_rule = 0;                              // rule R1: 0 = QCAT_R1_STRIPED, 1 = QCAT_R1_SCALAR (argv[3]; include/qcat_hip.h)
+static int qo_sg(const char* s1, int L, const char* s2, int M, int open, int extend, const int8_t* mat,
+                 int32_t* score, int32_t* end_query, int32_t* end_ref) {
+    return qo_sg_rule(s1, L, s2, M, open, extend, mat, g_rule, score, end_query, end_ref);
+}
 
 using namespace qabs;
 
@@ -101,7 +106,7 @@ static int check_plan(const char* name, const std::string* tpls, int rounds, int
         P::last1(h1, lo, lr);
         for (int t = 0; t < P::NT; ++t) {
             u32 val[ABS_NF + 1], endq[ABS_NI];
-            abs_decide(bd[t], lr[t], (unsigned)(L - 1), val, endq);
+            abs_decide(bd[t], lr[t], (unsigned)(L - 1), val, endq, g_rule != 0);
             const int M = (int)tpls[t].size();
             for (int b = 0; b < 32; ++b) {
                 int v = 0, e = 0;
@@ -172,7 +177,7 @@ static int check_padded(const char* name, const std::string* tpls, int rounds, i
         P::last0(h0, lo);
         P::last1(h1, lo, lr);
         u32 val[ABS_NF + 1], endq[ABS_NI];
-        abs_decide(bd[0], lr[0], (unsigned)(L - 1), val, endq);
+        abs_decide(bd[0], lr[0], (unsigned)(L - 1), val, endq, g_rule != 0);
         const int M = (int)tpls[0].size();
         for (int b = 0; b < 32; ++b) {
             int v = 0, e = 0;
@@ -243,7 +248,7 @@ static int check_multi(const char* name, const std::string* tpls, int rounds, in
         if (seen != P::NT) { fprintf(stderr, "%s: %d borders for %d templates\n", name, seen, P::NT); return 1000; }
         for (int t = 0; t < P::NT; ++t) {
             u32 val[ABS_NF + 1], endq[ABS_NI];
-            abs_decide(bd[t], lr[t], (unsigned)(L - 1), val, endq);
+            abs_decide(bd[t], lr[t], (unsigned)(L - 1), val, endq, g_rule != 0);
             const int M = (int)tpls[t].size();
             for (int b = 0; b < 32; ++b) {
                 int v = 0, e = 0;
@@ -300,6 +305,7 @@ struct Seqs { const char* a; const char* b; };
 int main(int argc, char** argv) {
     g_s = argc > 1 ? strtoull(argv[1], nullptr, 10) : 1;
     const int rounds = argc > 2 ? atoi(argv[2]) : 20;
+    g_rule = argc > 3 ? atoi(argv[3]) : 0;
     int bad = check_cells();
 #include "abs_host_cases.inc"
     return bad ? 1 : 0;

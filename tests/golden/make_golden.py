@@ -116,8 +116,11 @@ def install_standins():
                 def __init__(self, score, end_query, end_ref):
                     self.score, self.end_query, self.end_ref = score, end_query, end_ref
 
+            import os
+            NO_SSE2 = os.environ.get("QCAT_GOLDEN_NO_SSE2") == "1"      # make_r1_golden.py: the reference then binds plain `sg`
+
             def can_use_sse2():
-                return True
+                return not NO_SSE2
 
             def matrix_create(alphabet, match, mismatch):
                 return Matrix(alphabet, match, mismatch)
@@ -132,7 +135,16 @@ def install_standins():
                     _MEMO[key] = sg_independent.sg(s1, s2, open, extend, score)
                 return Result(*_MEMO[key])
 
-            sg = sg_striped_32
+            def sg(s1, s2, open, extend, matrix):
+                """plain parasail.sg: the same DP, the scalar routine's end-position order (sg_independent.sg rule="scalar")"""
+                CALLS["n"] += 1
+                CALLS["cells"] += len(s1) * len(s2)
+                flat, score = matrix.scorer()
+                key = ("scalar", s1, s2, open, extend, matrix.alphabet, flat)
+                if key not in _MEMO:
+                    CALLS["computed"] += 1
+                    _MEMO[key] = sg_independent.sg(s1, s2, open, extend, score, rule="scalar")
+                return Result(*_MEMO[key])
 
             class StatsResult(Result):
                 def __init__(self, score, end_query, end_ref, matches, length):
@@ -150,7 +162,14 @@ def install_standins():
                     _MEMO[key] = sg_independent.sg_stats(s1, s2, open, extend, score, alphabet=matrix.alphabet)
                 return StatsResult(*_MEMO[key])
 
-            sg_stats = sg_stats_striped_32
+            def sg_stats(s1, s2, open, extend, matrix):
+                CALLS["n"] += 1
+                CALLS["cells"] += len(s1) * len(s2)
+                flat, score = matrix.scorer()
+                key = ("stats-scalar", s1, s2, open, extend, matrix.alphabet, flat)
+                if key not in _MEMO:
+                    _MEMO[key] = sg_independent.sg_stats(s1, s2, open, extend, score, alphabet=matrix.alphabet, r1="scalar")
+                return StatsResult(*_MEMO[key])
             '''))
     sys.path.insert(0, d)
     return d
@@ -282,6 +301,13 @@ def simple_section(ref_scanner, cfg, fastq, inline, inline_names, seed0):
 
 
 def main():
+    # --r1-scalar (round 6): the stand-in reports no SSE2, so the UNMODIFIED reference binds plain `parasail.sg`
+    # (qcat/scanner_base.py:20-26) -- the other end-position rule (include/qcat_hip.h QCAT_R1_SCALAR).  A smaller set of
+    # cases goes to golden_r1_scalar.json: the shipped reads, the inline reads, the edge cases, synthetic reads of four
+    # kits and adapter-FREE reads of two (where the two rules part: the borders' maxima tie in low-scoring windows).
+    r1_scalar = "--r1-scalar" in sys.argv
+    if r1_scalar:
+        os.environ["QCAT_GOLDEN_NO_SSE2"] = "1"
     install_standins()
     if "--section" in sys.argv and sys.argv[sys.argv.index("--section") + 1] == "simple":
         ref_scanner, ref_base, ref_epi, ref_dual, ref_config = import_reference()
@@ -365,14 +391,34 @@ def main():
     run_case("edge:dual", "dual", None, edge)
 
     # 4. synthetic reads (re-generated by the tests from the stored parameters)
-    def synth_case(tag, mode, kit, t5, t3, e, n, seed, keep_rows=False):
+    def synth_case(tag, mode, kit, t5, t3, e, n, seed, keep_rows=False, bare=0.05):
         det = ref_scanner.factory(mode=mode, kit=kit)
         gen = {"seed": seed, "n": n, "tpl_5p": t5, "tpl_3p": t3, "error_rate": e,
-               "no_adapter_fraction": 0.05, "insert_len": 600, "lead_min": 5, "lead_max": 40}
-        reads = synth.synth_batch(n, seed, det.layouts, t5, t3, error_rate=e)
-        run_case("synth:%s:e%.2f" % (tag, e), mode, kit, reads, keep_rows=keep_rows, gen=gen)
+               "no_adapter_fraction": bare, "insert_len": 600, "lead_min": 5, "lead_max": 40}
+        reads = synth.synth_batch(n, seed, det.layouts, t5, t3, error_rate=e, no_adapter_fraction=bare)
+        run_case("synth:%s:e%.2f" % (tag, e) + (":bare" if bare == 1.0 else ""), mode, kit, reads, keep_rows=keep_rows, gen=gen)
 
     seed0 = 20260928
+    if r1_scalar:
+        import qcat.scanner_base as sb
+        assert sb.parasail_sg is parasail.sg and sb.parasail_sg is not parasail.sg_striped_32, "the reference did not bind parasail.sg"
+        cases[:] = [c for c in cases if c["name"].endswith(":kit") or c["name"] in ("inline:auto", "inline:dual", "edge:PBC096")]
+        synth_case("LWB001", "epi2me", "PBK004/LWB001", 1, 0, 0.08, 48, seed0 + 1)
+        synth_case("NBD104", "epi2me", "NBD103/NBD104", 1, 0, 0.08, 48, seed0 + 2)
+        synth_case("PBC096", "epi2me", "PBC096", 1, 0, 0.08, 48, seed0 + 3, keep_rows=True)
+        synth_case("DUAL", "dual", None, 1, 0, 0.08, 48, seed0 + 5)
+        synth_case("auto", "epi2me", None, 3, 2, 0.08, 32, seed0 + 7)
+        synth_case("NBD104", "epi2me", "NBD103/NBD104", 1, 0, 0.08, 96, seed0 + 50, bare=1.0)
+        synth_case("PBC096", "epi2me", "PBC096", 1, 0, 0.08, 96, seed0 + 51, bare=1.0)
+        synth_case("RBK004", "epi2me", "RBK004", 0, -1, 0.08, 64, seed0 + 52, bare=1.0)
+        with open(os.path.join(HERE, "golden_r1_scalar.json"), "w") as fh:
+            json.dump({"generator": "tests/golden/make_golden.py --r1-scalar",
+                       "template_order": "sorted by kit file name",
+                       "r1_rule": "scalar: the stand-in's can_use_sse2() is False, the unmodified reference binds parasail.sg (qcat/scanner_base.py:20-26)",
+                       "dp": "independent scalar Python DP tests/golden/sg_independent.py sg(rule='scalar')",
+                       "cases": cases}, fh, separators=(",", ":"))
+        print("golden_r1_scalar.json:", os.path.getsize(os.path.join(HERE, "golden_r1_scalar.json")), "bytes")
+        return
     for e in (0.0, 0.08, 0.15):
         # sorted order puts the 3p template first (index 0) and the 5p template second
         synth_case("LWB001", "epi2me", "PBK004/LWB001", 1, 0, e, 48, seed0 + 1, keep_rows=(e == 0.08))

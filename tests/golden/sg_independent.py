@@ -49,8 +49,14 @@ def scorer_from_table7(table7):
     return make_scorer("ATGCNX", flat, 7)
 
 
-def sg(s1, s2, gap_open, gap_extend, score):
-    """-> (score, end_query, end_ref).  s1 = query (read window / region), s2 = target."""
+def sg(s1, s2, gap_open, gap_extend, score, rule="striped"):
+    """-> (score, end_query, end_ref).  s1 = query (read window / region), s2 = target.
+    rule: "striped" = parasail.sg_striped_32's end-position order as recalled (above); "scalar" = plain parasail.sg's, the
+    routine the reference binds when parasail reports no SSE2 (qcat/scanner_base.py:20-26): the last column is examined while
+    the rows go by (strictly greater replaces -> the first row reaching its maximum), then the last row, target index
+    ascending, strictly greater replaces -- on a tie between the borders the last column keeps the result.  The switch is
+    shared with oracle/qcat_oracle.c (qo_sg_rule) and the device kernels (include/qcat_hip.h QCAT_R1_*)."""
+    assert rule in ("striped", "scalar")
     n, m = len(s1), len(s2)
     if n == 0 or m == 0:
         raise ValueError("empty sequence")
@@ -77,6 +83,16 @@ def sg(s1, s2, gap_open, gap_extend, score):
             if f > h:
                 h = f
             Ec[i], Fc[i], Hc[i] = e, f, h
+    if rule == "scalar":
+        last = H[m]
+        best, end_query, end_ref = None, 0, m - 1
+        for i in range(1, n + 1):
+            if best is None or last[i] > best:
+                best, end_query = last[i], i - 1
+        for j in range(1, m + 1):
+            if H[j][n] > best:
+                best, end_query, end_ref = H[j][n], n - 1, j - 1
+        return best, end_query, end_ref
     # last row: query fully consumed, scan the target positions in ascending order
     best, end_query, end_ref = None, n - 1, 0
     for j in range(1, m + 1):
@@ -94,7 +110,7 @@ def sg(s1, s2, gap_open, gap_extend, score):
     return best, end_query, end_ref
 
 
-def sg_stats(s1, s2, gap_open, gap_extend, score, alphabet="ATGCNX", rule="parasail"):
+def sg_stats(s1, s2, gap_open, gap_extend, score, alphabet="ATGCNX", rule="parasail", r1="striped"):
     """-> (score, end_query, end_ref, matches, length): the same alignment with the number of matches and of alignment
     columns along ONE optimal path.  `rule` is the switch shared with oracle/qcat_oracle.c qo_sg_stats and the device
     kernel k_sg_align (include/qcat_hip.h QCAT_STATS_*):
@@ -116,7 +132,7 @@ def sg_stats(s1, s2, gap_open, gap_extend, score, alphabet="ATGCNX", rule="paras
             return a.upper() == b.upper() and "ATGCNX".find(a.upper()) >= 0 or (a.upper() == b.upper())
         return code(a) == code(b)
     n, m = len(s1), len(s2)
-    best, end_query, end_ref = sg(s1, s2, gap_open, gap_extend, score)
+    best, end_query, end_ref = sg(s1, s2, gap_open, gap_extend, score, rule=r1)
     # recompute with statistics carried along (small inputs only: the simple-mode fixtures)
     H = [[0] * (n + 1) for _ in range(m + 1)]
     E = [[NEG] * (n + 1) for _ in range(m + 1)]

@@ -21,6 +21,27 @@ def golden():
     return _cache["g"]
 
 
+def golden_r1_scalar():
+    """the reference's outputs with plain `parasail.sg` bound (make_golden.py --r1-scalar; include/qcat_hip.h QCAT_R1_SCALAR)"""
+    if "r1" not in _cache:
+        with open(os.path.join(GOLDEN, "golden_r1_scalar.json")) as fh:
+            _cache["r1"] = json.load(fh)
+    return _cache["r1"]
+
+
+class r1_rule(object):
+    """with helpers.r1_rule("scalar"): ... -- descriptors built inside carry the rule (native.set_r1_rule)"""
+
+    def __init__(self, rule):
+        self.rule = rule
+
+    def __enter__(self):
+        self.old = native.set_r1_rule(self.rule)
+
+    def __exit__(self, *exc):
+        native.set_r1_rule(self.old)
+
+
 def inline_reads():
     with open(os.path.join(GOLDEN, "inline_reads.json")) as fh:
         return json.load(fh)["reads"]

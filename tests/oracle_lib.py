@@ -39,13 +39,16 @@ def _check(rc):
         raise RuntimeError("oracle error {}: {}".format(rc, lib().qo_last_error().decode()))
 
 
-def sg(s1, s2, open_, extend, table):
-    """(score, end_query, end_ref) of the oracle DP; ``table`` = int8 7x7 [target, query]."""
+def sg(s1, s2, open_, extend, table, rule=native.R1_STRIPED):
+    """(score, end_query, end_ref) of the oracle DP; ``table`` = int8 7x7 [target, query]; ``rule``: native.R1_STRIPED /
+    native.R1_SCALAR (include/qcat_hip.h QCAT_R1_*: which of the reference's two routines places the end)."""
     t = np.ascontiguousarray(table, dtype=np.int8)
     sc, eq, er = C.c_int32(), C.c_int32(), C.c_int32()
     b1, b2 = s1.encode("latin-1", "replace"), s2.encode("latin-1", "replace")
-    _check(lib().qo_sg(b1, len(b1), b2, len(b2), open_, extend, t.ctypes.data,
-                       C.byref(sc), C.byref(eq), C.byref(er)))
+    fn = lib().qo_sg_rule
+    fn.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    _check(fn(b1, len(b1), b2, len(b2), open_, extend, t.ctypes.data, int(rule), C.byref(sc), C.byref(eq), C.byref(er)))
     return sc.value, eq.value, er.value
 
 

@@ -25,9 +25,10 @@ def host_check(request, tmp_path_factory):
     return exe
 
 
+@pytest.mark.parametrize("rule", [0, 1], ids=["r1-striped", "r1-scalar"])       # include/qcat_hip.h QCAT_R1_*: abs_decide under both end-position rules
 @pytest.mark.parametrize("seed", [1, 20260929])
-def test_bit_sliced_adapter_arithmetic_equals_the_oracle_dp(host_check, seed):
-    p = subprocess.run([host_check, str(seed), "40"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+def test_bit_sliced_adapter_arithmetic_equals_the_oracle_dp(host_check, seed, rule):
+    p = subprocess.run([host_check, str(seed), "40" if rule == 0 else "12", str(rule)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-2000:] + p.stderr.decode()[-2000:]
     lines = [l for l in out.splitlines() if l.strip()]

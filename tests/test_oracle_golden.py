@@ -289,3 +289,65 @@ def test_path_count_dp_sees_ties():
     assert n == 2
     n, st = si.sg_unique_path("ACGT", "TTTT", 1, 1, score)                     # only the first target letter can pair with the last T
     assert n == 1 and st == (1, 3, 0, 1, 1)
+
+
+# ---- rule R1 under the reference's OTHER alignment routine (round 6) ------------------------------------------------
+R1_CASES = [c["name"] for c in helpers.golden_r1_scalar()["cases"]]
+
+
+@pytest.mark.parametrize("name", R1_CASES)
+def test_case_r1_scalar(name):
+    """the oracle with QCAT_R1_SCALAR against the unmodified reference run with plain `parasail.sg` bound
+    (qcat/scanner_base.py:20-26; tests/golden/make_golden.py --r1-scalar)"""
+    case = [c for c in helpers.golden_r1_scalar()["cases"] if c["name"] == name][0]
+    det = helpers.make_scanner(case["mode"], case["kit"])
+    reads = helpers.case_reads(case, det.layouts)
+    with helpers.r1_rule("scalar"):
+        desc = det.descriptor()
+    assert desc.desc.r1_rule == native.R1_SCALAR
+    recs, traces, rows = oracle_lib.scan(desc, reads, trace=True, rows=True)
+    helpers.assert_case_matches(case, recs, traces, rows, det.layouts)
+
+
+def test_r1_rules_part_on_adapter_free_reads():
+    """the two rules are not the same function: on the adapter-free fixture reads some end positions differ (and no score does)"""
+    case = [c for c in helpers.golden_r1_scalar()["cases"] if c["name"] == "synth:NBD104:e0.08:bare"][0]
+    det = helpers.make_scanner(case["mode"], case["kit"])
+    reads = helpers.case_reads(case, det.layouts)
+    _, tr_striped, _ = oracle_lib.scan(det.descriptor(), reads, trace=True, rows=True)
+    with helpers.r1_rule("scalar"):
+        desc = det.descriptor()
+    _, tr_scalar, _ = oracle_lib.scan(desc, reads, trace=True, rows=True)
+    nt = len(det.layouts)
+    differ = 0
+    for a, b in zip(tr_striped, tr_scalar):
+        assert list(a["tpl_raw"][:nt]) == list(b["tpl_raw"][:nt])
+        differ += int(list(a["tpl_end"][:nt]) != list(b["tpl_end"][:nt]))
+    assert differ > 0
+
+
+def test_sg_r1_scalar_vs_independent_dp():
+    """qo_sg_rule(QCAT_R1_SCALAR) against the independent scalar DP's rule="scalar" on seeded pairs (both matrices, ties forced by
+    short and low-complexity sequences), and both rules agree on the score"""
+    sys_path = os.path.join(helpers.GOLDEN)
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    import sg_independent
+    cfg = config.qcatConfig()
+    rng = np.random.RandomState(20260930)
+    for table, open_, ext, alpha in ((cfg.matrix.table, cfg.gap_open, cfg.gap_extend, "ACGTN"), (cfg.matrix_barcode.table, 1, 1, "ACGT")):
+        score = sg_independent.scorer_from_table7(table)
+        n_diff = 0
+        for _ in range(400):
+            k = int(rng.randint(2, 5))
+            s1 = "".join(alpha[i] for i in rng.randint(0, k, size=int(rng.randint(1, 60))))
+            s2 = "".join(alpha[i] for i in rng.randint(0, k, size=int(rng.randint(1, 50))))
+            want = sg_independent.sg(s1, s2, open_, ext, score, rule="scalar")
+            got = oracle_lib.sg(s1, s2, open_, ext, table, rule=native.R1_SCALAR)
+            assert got == want, (s1, s2, got, want)
+            striped = oracle_lib.sg(s1, s2, open_, ext, table)
+            assert striped == sg_independent.sg(s1, s2, open_, ext, score)
+            assert striped[0] == got[0]
+            n_diff += int(striped != got)
+        assert n_diff > 0
