@@ -510,8 +510,13 @@ int  qcat_fastq_demux(qcat_fastq* f, qcat_ctx* ctx, const qcat_kit* kit, const q
 /* ---- the same loop over a file of any size in bounded host memory (ABI 5) ----
  * replaces: the per-file loop of the reference driver as it STREAMS -- iter_fastx yields one batch at a time
  * (qcat/cli.py:235-306), the loop scans and writes it (:500-552) and keeps nothing but the two histograms (:366-383,
- * :531-534).  The file is taken in segments (opts->segment_bytes) through a three-stage pipeline: segment k + 1 is read
- * (pread into a reused buffer) and split into records while segment k is scanned and segment k - 1 is written; a segment is
+ * :531-534).  The file is taken in segments (opts->segment_bytes) through a three-stage pipeline: segment k + 1 is fetched
+ * (opts->stream_reader; the default, 2, points a window of ONE read-only mapping of the file at the segment and gives a
+ * written segment's pages back; 1 copies it with pread() into reused buffers: 2-3 x slower here) and split into records
+ * while segment k is scanned and segment k - 1 is written.  The mapped reader checks the file's size again before every
+ * window (QCAT_ERR_IO "the file changed size" as the pread reader's short read), but a file truncated WHILE a window of it
+ * is being read raises SIGBUS in the calling process -- as any mapped read does; callers whose inputs are still being
+ * written set stream_reader = 1.  A segment is
  * cut at a whole batch of batch_size reads counted from the start of the file whenever batches matter (kit_auto,
  * filter_barcodes).  Kits created with scan_middle_adapter (--detect-middle, scanner_base.py:593-595) upload whole reads.
  * Instead of one record per read the caller gets what the driver keeps: the histograms of the reads that passed the
@@ -519,7 +524,9 @@ int  qcat_fastq_demux(qcat_fastq* f, qcat_ctx* ctx, const qcat_kit* kit, const q
  * A record that is not a plain four-line FASTQ / two-line FASTA record: in the first segment QCAT_ERR_UNSUPPORTED before
  * anything is written (as qcat_fastq_open); later the call ends in front of that record's segment -- a batch boundary --
  * with stats->incomplete = 1, stats->next_offset = the file offset of the segment's first record and stats->n_reads = the
- * reads handled so far, and the caller's own parser carries on from there. */
+ * reads handled so far, and the caller's own parser carries on from there.  On ANY failure stats->n_reads / ->segments say
+ * how much had been written when it happened (QCAT_ERR_UNSUPPORTED with both 0: nothing was -- the caller may redo the
+ * file itself; anything else is an error behind written output). */
 typedef struct qcat_demux_hist {
     int32_t w0, w1;            /* in: row widths -- w0 >= the largest set 0, w1 >= the largest set 1 (dual mode), else 1 */
     int64_t* barcode;          /* out [n_templates * w0 * w1]: kept reads per (template t, barcode b, second barcode b2) at (t * w0 + b) * w1 + b2 */

@@ -179,10 +179,16 @@ def iter_fastx(reads_fx, fastq, batchsize, offset=0):
     """Yield (names, comments, seqs, quals) lists of at most ``batchsize`` reads; ``offset``: the byte of the file to start
     at (a record start: where the native loop handed the file back, ``_native_demux``)."""
     names, comments, seqs, quals = [], [], [], []
-    handle = open(reads_fx) if reads_fx else sys.stdin
+    if reads_fx and offset:
+        # a BYTE offset: seek the binary file, then wrap it -- a text handle only defines seek() for cookies of its own tell()
+        # (ADVICE r5: an arbitrary offset works by accident while the decoder is stateless)
+        import io
+        raw = open(reads_fx, "rb")
+        raw.seek(offset)
+        handle = io.TextIOWrapper(raw)
+    else:
+        handle = open(reads_fx) if reads_fx else sys.stdin
     try:
-        if offset:
-            handle.seek(offset)
         records = _fastq_records(handle) if fastq else ((t, s, None) for t, s in _fasta_records(handle))
         try:
             for title, seq, qual in records:

@@ -33,8 +33,7 @@
     X(BS_SERIAL, "1: the bit-sliced launches of a scan in line on the context's stream") \
     X(BS_SIDE, "1: ... on side streams whatever the batch size") \
     X(LEFTOVER_SIDE, "0 / 1: the left-over binary16 tiles behind / beside the bit-sliced launches") \
-    X(BS_DRAW, "0 / 1: the waves of a bit-sliced workgroup take a unit's barcodes round robin / draw them from a counter") \
-    X(BS_PIPE, "0 / 1: the next bit-sliced unit prepared beside the row loops of the current one never / whenever possible (default: from four super-tiles per CU)") \
+    X(BS_DRAW, "0 / 1: the waves of a bit-sliced workgroup take a unit's barcodes round robin / draw them from a counter (default 1; sets of 32 barcodes or more)") \
     X(BS_TRACE, "1: print the phase boundaries of one workgroup and the unit log of the bit-sliced launches") \
     X(BS_TRACE_UNITS, "1: ... and every unit") \
     X(BS_TRACE_WG, "the workgroup whose phase boundaries BS_TRACE prints (default 0)") \

@@ -782,7 +782,10 @@ class FastqFile(object):
         h = DemuxHist(w0=w0, w1=w1, barcode=barcode.ctypes.data_as(C.POINTER(C.c_int64)), adapter=adapter.ctypes.data_as(C.POINTER(C.c_int64)))
         st = DemuxStats()
         rc = hip.lib.qcat_fastq_demux_stream(os.fsencode(path), ctx.handle, kit.handle, C.byref(o), C.byref(h), C.byref(st))
-        if rc == -2:
+        if rc == -2 and int(st.segments) == 0 and int(st.n_reads) == 0:
+            # "not for the native loop" is only an answer while NOTHING has been written: the caller then parses the file
+            # itself from offset 0.  An UNSUPPORTED behind written segments (a scan call refused later in the file) is an
+            # error like any other -- redoing the file would duplicate the rows already out
             raise FastqFile.Unsupported((hip.lib.qcat_last_error() or b"").decode("utf-8", "replace"))
         hip.check(rc)
         return barcode, adapter, int(h.n_none), int(h.n_adapter_none), {

@@ -173,6 +173,7 @@ def init_comm(ctx, rank=None, world_size=None, environ=None, trace=None):
         if trace is not None:
             trace(name)
 
+    comm = None
     try:
         enter("rendezvous")
         uid = exchange_id(rank, world_size, native.comm_unique_id, environ)
@@ -194,7 +195,19 @@ def init_comm(ctx, rank=None, world_size=None, environ=None, trace=None):
         enter("ready")
         return comm
     except Exception as e:
-        raise RuntimeError("rank {} of {} failed in stage '{}': {}".format(rank, world_size, stage[0], e)) from e
+        #  a communicator that failed its proving all-reduce is closed, not leaked; the exception keeps its TYPE
+        # (callers catch TimeoutError / OSError of the rendezvous as such) and gains the rank and the stage it died in
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:                                            # noqa: BLE001 -- the first failure is the one to report
+                pass
+        note = "rank {} of {} failed in stage '{}'".format(rank, world_size, stage[0])
+        try:
+            wrapped = type(e)("{}: {}".format(note, e))
+        except Exception:                                                # noqa: BLE001 -- an exception type with another signature
+            wrapped = RuntimeError("{}: {}".format(note, e))
+        raise wrapped from e
 
 
 def _cgroup_cpu_quota():

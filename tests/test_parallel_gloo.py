@@ -253,7 +253,8 @@ def test_comm_start_up_failure_names_rank_and_stage(monkeypatch):
 
     seen = []
     monkeypatch.setattr(parallel, "exchange_id", lambda *a, **k: (_ for _ in ()).throw(OSError("no route")))
-    with pytest.raises(RuntimeError, match=r"rank 3 of 8 failed in stage 'rendezvous': no route"):
+    # (the exception keeps its type -- a caller that catches the rendezvous' OSError / TimeoutError still does -- and gains rank and stage)
+    with pytest.raises(OSError, match=r"rank 3 of 8 failed in stage 'rendezvous': no route"):
         parallel.init_comm(None, 3, 8, environ={}, trace=seen.append)
     assert seen == ["rendezvous"]
 
@@ -268,14 +269,20 @@ def test_comm_start_up_failure_names_rank_and_stage(monkeypatch):
         parallel.init_comm(None, 1, 2, environ={}, trace=seen.append)
     assert seen == ["rendezvous", "ncclCommInitRank"]
 
+    closed = []
+
     class Short:
         def __init__(self, *a):
             pass
 
         def allreduce(self, values, op=0):
             return [1.0]
+
+        def close(self):
+            closed.append(True)
     monkeypatch.setattr(native, "NativeComm", Short)
     seen.clear()
     with pytest.raises(RuntimeError, match=r"failed in stage 'first all-reduce': all-reduce of one per rank gave 1.0 for 2 ranks"):
         parallel.init_comm(None, 0, 2, environ={}, trace=seen.append)
     assert seen == list(parallel.COMM_STAGES[:3])
+    assert closed == [True]                   # a communicator that failed its proving all-reduce is closed, not leaked
