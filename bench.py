@@ -533,11 +533,11 @@ def cpu_legs(a, out, lib, kit, sp, desc, det, cfg, mode, recs):
     import oracle_lib
     ncpu = usable_cores()
 
-    def sample_reads(n):
+    def sample_reads(n, index=None):
         buf = np.zeros(4096, dtype=np.uint8)
         chunks, offs = [], np.zeros(n + 1, dtype=np.uint64)
         for i in range(n):
-            ln = lib.qcat_synth_read(kit.handle, C.byref(sp), i, buf.ctypes.data, buf.size)
+            ln = lib.qcat_synth_read(kit.handle, C.byref(sp), i if index is None else int(index[i]), buf.ctypes.data, buf.size)
             chunks.append(buf[:ln].tobytes())
             offs[i + 1] = offs[i] + ln
         return np.frombuffer(b"".join(chunks), dtype=np.uint8), offs
@@ -559,6 +559,13 @@ def cpu_legs(a, out, lib, kit, sp, desc, det, cfg, mode, recs):
     o = oracle_lib.scan(desc, packed=packed, threads=ncpu)
     all_cores = n_sample / (time.perf_counter() - t1)
     mism = int(np.count_nonzero(o != recs[:n_sample]))
+    # ... and a RANDOM subset of the whole shard, another one in every run (the timed sample is always the same
+    # first reads); the seed is reported
+    rseed = int.from_bytes(os.urandom(4), "little")
+    n_rand = int(min(a.reads, max(2000, min(n_sample, rate_all * 2.0))))
+    ridx = np.sort(np.random.RandomState(rseed).choice(a.reads, size=n_rand, replace=False)) if n_rand < a.reads else np.arange(a.reads)
+    o_rand = oracle_lib.scan(desc, packed=sample_reads(len(ridx), ridx), threads=ncpu)
+    mism_rand = int(np.count_nonzero(o_rand != recs[ridx]))
     # reference-defined DP cells per read on the probe (second figure)
     lays = det.layouts
     cells_a = cells_b = 0
@@ -582,7 +589,8 @@ def cpu_legs(a, out, lib, kit, sp, desc, det, cfg, mode, recs):
     out["cpu_baseline"] = {"value": round(all_cores, 1), "unit": "reads/s", "cores": ncpu, "kind": "port",
                            "sample": "first %d reads of rank 0's shard, oracle/qcat_oracle.c with OpenMP over "
                                      "%d threads of %s (1 thread: %.0f reads/s on %d reads)" % (n_sample, ncpu, cpu_model, one_thread, probe)}
-    out["parity"] = {"checked_reads": n_sample, "mismatches_vs_oracle": mism}
+    out["parity"] = {"checked_reads": n_sample + len(ridx), "mismatches_vs_oracle": mism + mism_rand,
+                     "first_reads": n_sample, "random_reads": int(len(ridx)), "random_seed": rseed, "mismatches_random": mism_rand}
     out["dp_cells"] = {"unit": "reference-defined DP cell updates (SURVEY.md 8d) -- a plain rate, no ceiling attached",
                        "adapter_cells_per_read": round(cells_a, 1), "barcode_cells_per_read": round(cells_b, 1),
                        "region_path_fraction": round(region_frac, 4),

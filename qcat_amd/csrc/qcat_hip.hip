@@ -87,6 +87,10 @@ static void qcat_options_from_env() {
         g_qcat_opt[i].store(e ? (*e ? (int64_t)atoll(e) : 1) : QOPT_UNSET, std::memory_order_relaxed);
     }
 }
+// (Round 6, measured and not kept: GPU_MAX_HW_QUEUES = 12 set from here at load -- the runtime's default of four hardware queues
+// lets four of a small batch's side-by-side launches run at a time.  With twelve every cross-stream dependency of a call
+// becomes a cross-QUEUE signal of 40-50 us where it was an in-queue barrier of 6: the 4000-read kit-auto call 0.81 -> 1.19 ms,
+// config 2 0.99 -> 1.66 ms, the dual kit 3.84 -> 5.08 ms, config 3 31.9 -> 32.8 ms; profiles/r06_ab_hw_queues.txt.)
 static struct QcatOptInit { QcatOptInit() { qcat_options_from_env(); } } g_qcat_opt_init;
 static int qcat_opt_index(const char* name) {
     if (!name) return -1;
@@ -475,6 +479,10 @@ struct qcat_ctx {
     // pinned staging of window-only uploads (qcat_scan_batch): compact bases, offsets, real lengths
     uint8_t* pin_bases = nullptr; size_t cap_pin_bases = 0;
     uint64_t* pin_offsets = nullptr; uint32_t* pin_len = nullptr; size_t cap_pin_reads = 0;
+    uint8_t* pin_ret = nullptr; size_t cap_pin_ret = 0;     // what a host-buffer call brings back (records, votes, counts): copies into PINNED
+                                                            // memory are one DMA each; into the caller's pageable arrays the runtime stages
+                                                            // every one through a copy kernel and a host memcpy (round 6: five of them were
+                                                            // 100 us of a 4000-read kit-auto call)
     HostPipeline* pipe = nullptr;                  // chunked host-buffer scans (host_pipeline.inc), created on first use
     std::vector<qcat_ctx*> helpers;                // contexts of the kit-auto file loop's other workers (fastq_host.inc), created on first use
     PackedScratch packed;
@@ -570,6 +578,7 @@ extern "C" void qcat_ctx_destroy(qcat_ctx* c) {
     if (c->pin_bases) (void)hipHostFree(c->pin_bases);
     if (c->pin_offsets) (void)hipHostFree(c->pin_offsets);
     if (c->pin_len) (void)hipHostFree(c->pin_len);
+    if (c->pin_ret) (void)hipHostFree(c->pin_ret);
     pipeline_free(c->pipe);
     (void)hipFree(c->mid_tables); (void)hipFree(c->mid_generic); (void)hipFree(c->mid_slot); (void)hipFree(c->mid_sorted);
     (void)hipFree(c->mid_len); (void)hipFree(c->mid_fallback); (void)hipFree(c->mid_recs); (void)hipFree(c->mid_bests);
@@ -1106,6 +1115,40 @@ extern "C" int qcat_ctx_fetch_counts(qcat_ctx* c, int64_t* counts, int32_t n_buc
     return 0;
 }
 
+// records and counts of the last scan back to a host-buffer caller: through the context's pinned block while that stays small
+// (a call of the reference's own shape: 4000 reads = 96 KB) -- one DMA each and ONE wait -- else straight to the caller's arrays
+static int fetch_back(qcat_ctx* c, qcat_result* out, uint32_t n_reads, int64_t* counts_add, int32_t n_buckets) {
+    const size_t bytes_rec = (size_t)n_reads * sizeof(qcat_result), off_cnt = (bytes_rec + 63) / 64 * 64;
+    const size_t need = off_cnt + (counts_add ? (size_t)n_buckets * 8 : 0);
+    if (need > (8u << 20)) {
+        int rc = qcat_ctx_fetch_results(c, out, n_reads);
+        if (!rc && counts_add) {
+            std::vector<int64_t> tmp((size_t)n_buckets);
+            rc = qcat_ctx_fetch_counts(c, tmp.data(), n_buckets);
+            if (!rc) for (size_t i = 0; i < tmp.size(); ++i) counts_add[i] += tmp[i];
+        }
+        return rc;
+    }
+    if (n_reads != c->last_n_reads || (counts_add && n_buckets != c->last_buckets)) return set_err(QCAT_ERR_ARG, "sizes do not match the last scan");
+    HIPCHK(hipSetDevice(c->device));
+    if (need > c->cap_pin_ret) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->pin_ret) (void)hipHostFree(c->pin_ret);
+        c->pin_ret = nullptr; c->cap_pin_ret = 0;
+        HIPCHK(hipHostMalloc((void**)&c->pin_ret, need + need / 4 + 4096));
+        c->cap_pin_ret = need + need / 4 + 4096;
+    }
+    if (n_reads) HIPCHK_DRAIN(c->stream, hipMemcpyAsync(c->pin_ret, c->results, bytes_rec, hipMemcpyDeviceToHost, c->stream));
+    if (counts_add) HIPCHK_DRAIN(c->stream, hipMemcpyAsync(c->pin_ret + off_cnt, c->counts, (size_t)n_buckets * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_reads) memcpy(out, c->pin_ret, bytes_rec);
+    if (counts_add) {
+        const int64_t* tmp = reinterpret_cast<const int64_t*>(c->pin_ret + off_cnt);
+        for (int32_t i = 0; i < n_buckets; ++i) counts_add[i] += tmp[i];
+    }
+    return 0;
+}
+
 extern "C" void* qcat_ctx_stream(qcat_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int64_t qcat_ctx_tiny_ends(const qcat_ctx* c) { return c ? (int64_t)c->last_tiny_ends : -1; }
 // reads whose interior the latest --detect-middle scan put on the one-wave kernels (k_midw_*: interiors the packed interior scan
@@ -1545,8 +1588,16 @@ static int scan_batch_pipelined(qcat_ctx* c, qcat_kit* kit, const ReadView& rv,
         cuts.push_back(n_reads);
     }
     const uint32_t n_chunks = (uint32_t)cuts.size() - 1;
+    // staging for the LARGEST chunk of this call, and for the second slot only when there is a second chunk (round 6: a segment of
+    // the file loop is one chunk of 40-180 k reads -- sizing both slots for 256 k reads pinned 157 MB, 0.2 ms per MiB, in front
+    // of the first segment's scan: 42 ms of a 160 ms run); a later, bigger call grows them with headroom
+    uint32_t largest = 0;
+    for (uint32_t q = 0; q < n_chunks; ++q) largest = std::max(largest, cuts[q + 1] - cuts[q]);
     for (PipeStage& st : p->st) {
-        const size_t need_reads = (size_t)chunk + 1, need_bases = (size_t)chunk * keep + 2 * BATCH_SLACK;
+        if (&st != &p->st[0] && n_chunks < 2) break;
+        size_t need_reads = (size_t)largest + 1, need_bases = (size_t)largest * keep + 2 * BATCH_SLACK;
+        if (need_reads > st.cap_reads && st.cap_reads) need_reads = std::min<size_t>((size_t)chunk + 1, need_reads + need_reads / 2);
+        if (need_bases > st.cap_bases && st.cap_bases) need_bases = std::min<size_t>((size_t)chunk * keep + 2 * BATCH_SLACK, need_bases + need_bases / 2);
         if (need_reads > st.cap_reads) {
             if (st.pin_offsets) (void)hipHostFree(st.pin_offsets);
             if (st.pin_len) (void)hipHostFree(st.pin_len);
@@ -1773,12 +1824,7 @@ extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
         if (!rc) { c->last_n_reads = n_reads; c->last_buckets = kit->hk.dk.n_buckets; }      // (a replay does not pass through scan_resident_impl)
     } else rc = scan_resident_impl(c, kit, b, debug, bc_rows ? row_stride : 0);
     if (rc) (void)hipStreamSynchronize(c->stream);          // (the upload may still be reading the context's pinned staging)
-    if (!rc) rc = qcat_ctx_fetch_results(c, out, n_reads);
-    if (!rc && counts) {
-        std::vector<int64_t> tmp((size_t)kit->hk.dk.n_buckets);
-        rc = qcat_ctx_fetch_counts(c, tmp.data(), kit->hk.dk.n_buckets);
-        if (!rc) for (size_t i = 0; i < tmp.size(); ++i) counts[i] += tmp[i];
-    }
+    if (!rc) rc = fetch_back(c, out, n_reads, counts, kit->hk.dk.n_buckets);
     if (!rc && debug && n_reads) {
         const int ends = kit->hk.dk.ends == QCAT_ENDS_5P ? 1 : 2;
         const size_t n_ends = (size_t)n_reads * ends;
@@ -1909,17 +1955,26 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
     };
     if ((rc = api_graph_run(c, c->api_graph, kit, kd, b, batch_reads, enqueue,
                             [&] { c->packed.kit_slot_dev = chosen_dev; c->packed.kit_slot_span = slot_span; }))) return rc;
-    unsigned long long hv[MAX_T], hf[MAX_T];
-    std::vector<int32_t> chosen((size_t)nb, -1);
-    std::vector<int64_t> tmp(counts ? (size_t)hk.n_buckets : 0);
-    if (!batch_reads) {
-        HIPCHK_DRAIN(c->stream, hipMemcpyAsync(hv, d, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK_DRAIN(c->stream, hipMemcpyAsync(hf, d_first, MAX_T * 8, hipMemcpyDeviceToHost, c->stream));
+    // what comes back, through the context's pinned block: the records, the vote buffer as it lies on the device (votes, first
+    // voting reads, chosen slots: one allocation), the counts -- three DMAs
+    const size_t bytes_rec = (size_t)n_reads * sizeof(qcat_result), bytes_vote = 2 * (size_t)nb * MAX_T * 8 + (size_t)nb * 4;
+    const size_t off_vote = (bytes_rec + 63) / 64 * 64, off_cnt = (off_vote + bytes_vote + 63) / 64 * 64;
+    const size_t need_ret = off_cnt + (size_t)hk.n_buckets * 8;
+    if (need_ret > c->cap_pin_ret) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->pin_ret) (void)hipHostFree(c->pin_ret);
+        c->pin_ret = nullptr; c->cap_pin_ret = 0;
+        HIPCHK(hipHostMalloc((void**)&c->pin_ret, need_ret + need_ret / 4));
+        c->cap_pin_ret = need_ret + need_ret / 4;
     }
-    HIPCHK_DRAIN(c->stream, hipMemcpyAsync(chosen.data(), chosen_dev, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK_DRAIN(c->stream, hipMemcpyAsync(out, c->results, (size_t)n_reads * sizeof(qcat_result), hipMemcpyDeviceToHost, c->stream));
-    if (counts) HIPCHK_DRAIN(c->stream, hipMemcpyAsync(tmp.data(), c->counts, (size_t)hk.n_buckets * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK_DRAIN(c->stream, hipMemcpyAsync(c->pin_ret, c->results, bytes_rec, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK_DRAIN(c->stream, hipMemcpyAsync(c->pin_ret + off_vote, d, bytes_vote, hipMemcpyDeviceToHost, c->stream));
+    if (counts) HIPCHK_DRAIN(c->stream, hipMemcpyAsync(c->pin_ret + off_cnt, c->counts, (size_t)hk.n_buckets * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(out, c->pin_ret, bytes_rec);
+    const unsigned long long* hv = reinterpret_cast<const unsigned long long*>(c->pin_ret + off_vote);
+    const unsigned long long* hf = hv + (size_t)nb * MAX_T;
+    const int32_t* chosen = reinterpret_cast<const int32_t*>(hf + (size_t)nb * MAX_T);
     if (!batch_reads)
         for (int t = 0; t < hk.nt; ++t) {
             if (votes) votes[t] += (int64_t)hv[t];
@@ -1928,7 +1983,10 @@ static int scan_batch_auto_impl(qcat_ctx* c, const qcat_kit* ckit, const uint8_t
     bool all_voted = true;
     for (uint32_t q = 0; q < nb; ++q) { chosen_kit_slot[q] = chosen[q]; all_voted = all_voted && chosen[q] >= 0; }
     if (!all_voted) return set_err(QCAT_ERR_DEVICE, "qcat_scan_batch_auto: no read voted");
-    if (counts) for (size_t i = 0; i < tmp.size(); ++i) counts[i] += tmp[i];
+    if (counts) {
+        const int64_t* tmp = reinterpret_cast<const int64_t*>(c->pin_ret + off_cnt);
+        for (size_t i = 0; i < (size_t)hk.n_buckets; ++i) counts[i] += tmp[i];
+    }
     return 0;
 }
 

@@ -15,6 +15,16 @@ import numpy as np
 
 from . import adapters, config, native
 from .adapters import Barcode
+import threading  # noqa: E402
+
+_SHARED_CONTEXTS = {}            # (thread id, device) -> native.NativeContext, see BarcodeScanner._context
+
+
+def release_contexts():
+    """destroy the contexts the scanners of this process share (device staging, pinned buffers); scanners made afterwards
+    start new ones"""
+    _SHARED_CONTEXTS.clear()
+
 
 
 def build_return_dict(best_barcode, best_barcode_score, best_adapter, best_adapter_end,
@@ -60,13 +70,13 @@ class Alignment(object):
         self.matches, self.length = int(rec["matches"]), int(rec["length"])
 
 
-_helper_ctx = {}
-
-
 def _ctx(device=0):
-    if device not in _helper_ctx:
-        _helper_ctx[device] = native.NativeContext(device)
-    return _helper_ctx[device]
+    """the calling thread's context on `device` -- the one the scanner objects share (BarcodeScanner._context)"""
+    key = (threading.get_ident(), device)
+    ctx = _SHARED_CONTEXTS.get(key)
+    if ctx is None:
+        ctx = _SHARED_CONTEXTS[key] = native.NativeContext(device)
+    return ctx
 
 
 def _sg(queries, targets, gap_open, gap_extend, matrix, with_stats=False):
@@ -228,8 +238,15 @@ class BarcodeScanner(object):
         return kit
 
     def _context(self):
+        """the calling thread's context on this scanner's device.  Scanner objects SHARE it (round 6): a context owns the device
+        staging and the pinned buffers of its calls, and making them anew for every scanner object -- the driver makes one per
+        run -- was 80 ms in front of a run's first scan and 50 ms of hipFree behind it; `release_contexts()` gives them back."""
         if self._ctx is None:
-            self._ctx = native.NativeContext(self.device)
+            key = (threading.get_ident(), self.device)
+            ctx = _SHARED_CONTEXTS.get(key)
+            if ctx is None:
+                ctx = _SHARED_CONTEXTS[key] = native.NativeContext(self.device)
+            self._ctx = ctx
         return self._ctx
 
     def _record_to_dict(self, rec, layouts):
