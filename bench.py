@@ -393,6 +393,55 @@ def from_fastq(ctx, kit, det, mode, hb, ho, n, recs):
                     "it); TSV bytes identical between the two, records of the whole-file call identical to the resident scan's; host-bound"}
 
 
+def from_fastq_sharded(det, cfg, hb, ho, n, comm, rank, world):
+    """N > 1 (round 6): ONE FASTQ file over the ranks -- rank 0 writes the first min(n, 1 M) reads of its shard as a file, every
+    rank takes its whole batches of 4000 reads (parallel.file_shards: qcat_fastq_batch_offsets), demultiplexes its byte range
+    with a TSV of its own (qcat_fastq_demux_stream with range_begin / range_end), the histograms meet in one all-reduce and
+    rank 0 strings the TSV shards together.  Strong scaling of a small file: what it shows is that the ranks can share a file,
+    not a rate to compare with the resident one.  Never raises: a failure is reported in the line."""
+    import shutil
+    import tempfile
+    try:
+        m = min(n, 1000000)
+        tmp = os.path.join(tempfile.gettempdir(), "qcat_bench_shared_" + parallel.job_nonce().hex())
+        path = os.path.join(tmp, "reads.fastq")
+        if rank == 0:
+            os.makedirs(tmp, exist_ok=True)
+            raw = hb[:int(ho[m])].tobytes()
+            qual = b"I" * 65536
+            with open(path, "wb", buffering=0) as fh:
+                for i0 in range(0, m, 16384):
+                    fh.write(b"".join(b"@r%d ch=%d\n%s\n+\n%s\n" % (i, 1 + i % 512, raw[int(ho[i]):int(ho[i + 1])],
+                                                                       qual[:int(ho[i + 1] - ho[i])] if int(ho[i + 1] - ho[i]) <= 65536 else b"I" * int(ho[i + 1] - ho[i]))
+                                      for i in range(i0, min(m, i0 + 16384))))
+        comm.barrier()
+        shards, n_reads, _ = parallel.file_shards(path, world)
+        tsv = os.path.join(tmp, "calls.tsv")
+        best = None
+        for _ in range(2):                               # (the first call sizes the context's staging buffers)
+            comm.barrier()
+            t1 = time.perf_counter()
+            res = parallel.demux_file_shard(det, path, rank, world, cfg, tsv_path=tsv, trim=True, comm=comm, shards=shards)
+            dt = comm.allreduce([time.perf_counter() - t1], native.REDUCE_MAX)[0]
+            best = dt if best is None else min(best, dt)
+        out = None
+        if rank == 0:
+            parallel.merge_shards(tsv, world)
+            with open(tsv, "rb") as fh:
+                rows = sum(chunk.count(b"\n") for chunk in iter(lambda: fh.read(1 << 24), b""))
+            ok = n_reads == m and res[4].get("n_reads_total", res[4]["n_reads"]) == m and rows == m
+            out = {"value": round(m / best, 1), "unit": "reads/s", "reads": m, "ranks": world, "seconds": round(best, 4),
+                   "shards_bytes": [e - s for s, e in shards], "rows_and_counts_complete": bool(ok),
+                   "note": "one file of %d reads over %d ranks: whole batches of 4000 reads per rank, a TSV shard per rank, histograms "
+                           "all-reduced, shards strung together by rank 0 (qcat_amd/parallel.py); max over the ranks" % (m, world)}
+        comm.barrier()
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
+        return out
+    except Exception as e:                               # noqa: BLE001 -- a diagnostic leg must not take the bench line down
+        return {"error": "%s: %s" % (type(e).__name__, e)} if rank == 0 else None
+
+
 def host_inclusive(a, hip, lib, ctx, kit, cfg, ends, batch, sp, n_bases, recs, comm, world, det, mode):
     n = a.reads if world == 1 else min(a.reads, 2000000)
     small = None
@@ -431,6 +480,8 @@ def host_inclusive(a, hip, lib, ctx, kit, cfg, ends, batch, sp, n_bases, recs, c
     up = int(ho[n]) if a.workload == "middle" else int(np.minimum(np.diff(ho).astype(np.int64), keep).sum())
     # (the native FASTQ driver scans both ends, like qcat's own driver: workloads on a both-ends kit, one process)
     fq_leg = from_fastq(ctx, kit, det, mode, hb, ho, n, recs) if (world == 1 and ends == native.ENDS_BOTH and a.workload != "middle") else None
+    if world > 1 and comm is not None and ends == native.ENDS_BOTH and a.workload != "middle":
+        fq_leg = from_fastq_sharded(det, cfg, hb, ho, n, comm, parallel.rank_env()[0], world)
     return {"from_fastq": fq_leg, "value": round(world * n / best, 1), "unit": "reads/s", "reads_per_gpu": n, "host_threads_per_rank":
             int(os.environ.get("QCAT_HOST_THREADS", "0")) or min(usable_cores(), 16),
             "note": "qcat_scan_batch from pageable host memory (%.0f MB of reads per rank), records identical to the "

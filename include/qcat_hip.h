@@ -491,6 +491,12 @@ typedef struct qcat_demux_opts {
     int32_t stream_reader;     /* qcat_fastq_demux_stream: how a segment's bytes are fetched -- 0: the default, 1: pread() into reused buffers,
                                 * 2: a mapped window of the file per segment */
     uint64_t segment_bytes;    /* qcat_fastq_demux_stream: bytes of the file per segment (0: 256 MiB) */
+    /* ABI 6: a SHARD of the file -- qcat_fastq_demux_stream handles the records in the bytes [range_begin, range_end) only
+     * (both record starts, e.g. from qcat_fastq_batch_offsets; range_end 0: the end of the file).  Batches are counted from
+     * range_begin, so a shard that starts at a batch boundary of the whole file votes and filters exactly like the one-rank run
+     * (qcat/cli.py:500-513: vote and filter are per batch); the outputs are the shard's own (the caller gives every rank its own
+     * descriptors / directory and strings the shards together in rank order), stats->next_offset stays a file offset. */
+    uint64_t range_begin, range_end;
 } qcat_demux_opts;
 typedef struct qcat_demux_stats {
     uint64_t n_reads, n_skipped, file_bytes;
@@ -534,6 +540,15 @@ typedef struct qcat_demux_hist {
     int64_t n_none;            /* out: kept reads without a barcode call */
     int64_t n_adapter_none;    /* out: kept reads without an adapter */
 } qcat_demux_hist;
+/* replaces: nothing in the reference (one process, one file); what N ranks need to split ONE file into whole batches of the
+ * driver's loop (qcat/cli.py:500: the unit of the kit vote and of --filter-barcodes, SURVEY.md 8e "what does not shard").
+ * One pass of the streamed reader over the file: (*offsets)[i] = the file offset of record i * batch_size, for i <
+ * *n_batches = ceil(n_reads / batch_size), and (*offsets)[*n_batches] = where the plain records end (*next_offset: the file
+ * size, or the offset of the segment that holds the first record the native loop does not take -- the caller's own parser
+ * carries on there, after all shards).  The array is malloc()ed: qcat_free() it.  QCAT_ERR_UNSUPPORTED: not a plain file. */
+int  qcat_fastq_batch_offsets(const char* path, uint32_t batch_size, uint64_t segment_bytes, uint64_t** offsets,
+                              uint64_t* n_batches, uint64_t* n_reads, uint64_t* next_offset);
+void qcat_free(void* p);
 int  qcat_fastq_demux_stream(const char* path, qcat_ctx* ctx, const qcat_kit* kit, const qcat_demux_opts* opts,
                              qcat_demux_hist* hist, qcat_demux_stats* stats);
 /* the reader stage alone (no device): reads and sequence letters of the file, taken in the same segments (batch_size > 0: cut at

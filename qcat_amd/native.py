@@ -102,7 +102,8 @@ class DemuxOpts(C.Structure):
                 ("tsv", C.c_int32), ("tsv_fd", C.c_int32), ("out_fd", C.c_int32), ("out_dir", C.c_char_p),
                 ("kit_name", C.POINTER(C.c_char_p)), ("bc_name", C.POINTER(C.POINTER(C.c_char_p))),
                 ("bc_id", C.POINTER(C.POINTER(C.c_int32))), ("bc2_id", C.POINTER(C.POINTER(C.c_int32))),
-                ("filter_barcodes", C.c_int32), ("stream_reader", C.c_int32), ("segment_bytes", C.c_uint64)]
+                ("filter_barcodes", C.c_int32), ("stream_reader", C.c_int32), ("segment_bytes", C.c_uint64),
+                ("range_begin", C.c_uint64), ("range_end", C.c_uint64)]
 
 
 class DemuxStats(C.Structure):
@@ -364,6 +365,9 @@ class HipLibrary(object):
             "qcat_fastq_read_info": (C.c_int, [vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(u32), C.POINTER(C.c_uint64), C.POINTER(u32)]),
             "qcat_fastq_demux": (C.c_int, [vp, vp, vp, C.POINTER(DemuxOpts), vp, vp, C.POINTER(DemuxStats)]),
             "qcat_fastq_demux_stream": (C.c_int, [C.c_char_p, vp, vp, C.POINTER(DemuxOpts), C.POINTER(DemuxHist), C.POINTER(DemuxStats)]),
+            "qcat_fastq_batch_offsets": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_uint64),
+                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+            "qcat_free": (None, [vp]),
             "qcat_fastq_stream_count": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
             "qcat_comm_unique_id": (C.c_int, [vp]),
@@ -708,7 +712,8 @@ class FastqFile(object):
         return int(to.value), int(tl.value), int(so.value), int(sl.value)
 
     @staticmethod
-    def _demux_opts(layouts, dual, batch_size, kit_auto, trim, min_read_length, tsv_fd, out_fd, out_dir, filter_barcodes, segment_bytes, reader=0):
+    def _demux_opts(layouts, dual, batch_size, kit_auto, trim, min_read_length, tsv_fd, out_fd, out_dir, filter_barcodes, segment_bytes, reader=0,
+                    byte_range=None):
         """a qcat_demux_opts and the buffers it points to"""
         n_t = len(layouts)
         keep = []
@@ -733,7 +738,8 @@ class FastqFile(object):
                       out_dir=os.fsencode(out_dir) if out_dir else None,
                       kit_name=C.cast(kit_names, C.POINTER(C.c_char_p)), bc_name=C.cast(bc_name, C.POINTER(C.POINTER(C.c_char_p))),
                       bc_id=C.cast(bc_id, C.POINTER(C.POINTER(C.c_int32))), bc2_id=C.cast(bc2_id, C.POINTER(C.POINTER(C.c_int32))),
-                      filter_barcodes=1 if filter_barcodes else 0, stream_reader=int(reader), segment_bytes=int(segment_bytes or 0))
+                      filter_barcodes=1 if filter_barcodes else 0, stream_reader=int(reader), segment_bytes=int(segment_bytes or 0),
+                      range_begin=int(byte_range[0]) if byte_range else 0, range_end=int(byte_range[1]) if byte_range else 0)
         return o, keep
 
     def demux(self, ctx, kit, layouts, dual, batch_size=4000, kit_auto=False, trim=False, min_read_length=0,
@@ -752,6 +758,23 @@ class FastqFile(object):
                                "parse_s": st.parse_s, "scan_s": st.scan_s, "write_s": st.write_s, "total_s": st.total_s}
 
     @staticmethod
+    def batch_offsets(path, batch_size=4000, segment_bytes=0):
+        """qcat_fastq_batch_offsets: (offsets, n_reads, next_offset) -- offsets[i] = file offset of read i * batch_size (one per
+        batch of the driver's loop, numpy uint64) and offsets[-1] = where the plain records end (no device needed)."""
+        hip = HipLibrary.get()
+        ptr = C.POINTER(C.c_uint64)()
+        nb, nr, nxt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc = hip.lib.qcat_fastq_batch_offsets(os.fsencode(path), int(batch_size), int(segment_bytes), C.byref(ptr), C.byref(nb), C.byref(nr), C.byref(nxt))
+        if rc == -2:
+            raise FastqFile.Unsupported((hip.lib.qcat_last_error() or b"").decode("utf-8", "replace"))
+        hip.check(rc)
+        try:
+            offs = np.ctypeslib.as_array(ptr, shape=(int(nb.value) + 1,)).copy()
+        finally:
+            hip.lib.qcat_free(ptr)
+        return offs, int(nr.value), int(nxt.value)
+
+    @staticmethod
     def stream_count(path, segment_bytes=0, batch_size=0, reader=0):
         """qcat_fastq_stream_count: (reads, sequence letters, next offset, segments) of a file through the reader stage of
         qcat_fastq_demux_stream (no device needed)."""
@@ -765,15 +788,16 @@ class FastqFile(object):
 
     @staticmethod
     def demux_stream(path, ctx, kit, layouts, dual, batch_size=4000, kit_auto=False, trim=False, min_read_length=0,
-                     tsv_fd=None, out_fd=None, out_dir=None, filter_barcodes=False, segment_bytes=0, reader=0):
+                     tsv_fd=None, out_fd=None, out_dir=None, filter_barcodes=False, segment_bytes=0, reader=0, byte_range=None):
         """qcat_fastq_demux_stream: the file in segments through read | scan | write, host memory independent of its size.
+        ``byte_range`` = (begin, end): a rank's shard of the file, both record starts (``batch_offsets``; end 0: the file's end).
         Returns (barcode counts [template][barcode][second barcode], adapter counts [template], reads without a barcode,
         reads without an adapter, stats dict); ``stats["incomplete"]``: the loop ended at ``stats["next_offset"]`` in front of
         a record that is not plain -- the caller's own parser carries on from there.  Raises ``Unsupported`` when that is the
         case for the very first segment (nothing has been written)."""
         hip = HipLibrary.get()
         o, _keep = FastqFile._demux_opts(layouts, dual, batch_size, kit_auto, trim, min_read_length, tsv_fd, out_fd, out_dir,
-                                         filter_barcodes, segment_bytes, reader)
+                                         filter_barcodes, segment_bytes, reader, byte_range)
         n_t = len(layouts)
         w0 = max(1, max(len(l.get_barcode_set(0) or ()) for l in layouts))
         w1 = max(1, max(len(l.get_barcode_set(1) or ()) for l in layouts)) if dual else 1

@@ -326,3 +326,123 @@ def launch(n_ranks, argv, environ=None):
                     q.terminate()
         time.sleep(0.05)
     return worst
+
+
+# ---- ONE file over N ranks (round 6) ---------------------------------------------------------------------------------------
+# The reference driver is one process and one file (qcat/cli.py:445-563).  Its unit is the BATCH of 4000 reads: the kit vote and
+# --filter-barcodes are decided per batch (cli.py:500-513, scanner_base.py:690-733; SURVEY.md 8e "what does not shard"), the
+# reads of a batch are independent.  So a file shards at batch boundaries: every rank learns where the batches start
+# (qcat_fastq_batch_offsets: one pass of the record splitter, no device), takes a contiguous run of WHOLE batches, demultiplexes
+# its byte range with outputs of its own (qcat_fastq_demux_stream, range_begin / range_end), and the ranks' outputs strung
+# together in rank order ARE the one-rank outputs, byte for byte; the histograms meet in one all-reduce.
+
+def file_shards(path, world_size, batch_size=4000, segment_bytes=0):
+    """[(begin, end)] byte ranges of `path`, one per rank (empty ranges for ranks beyond the batches), plus (n_reads, next_offset):
+    whole batches of `batch_size` reads, contiguous, in rank order.  next_offset < file size: the plain records end there and the
+    caller's own parser takes the rest (after the last shard)."""
+    from . import native
+    offs, n_reads, next_offset = native.FastqFile.batch_offsets(path, batch_size, segment_bytes)
+    n_batches = len(offs) - 1
+    shards = []
+    for r in range(world_size):
+        b0, b1 = shard_range(n_batches, r, world_size)
+        shards.append((int(offs[b0]), int(offs[b1])))
+    return shards, n_reads, next_offset
+
+
+def shard_paths(path, rank):
+    """where rank `rank` writes its part of the output `path` (a TSV / FASTQ file or a per-barcode directory)"""
+    return "%s.rank%d" % (path, rank)
+
+
+def demux_file_shard(detector, reads_fq, rank, world_size, qcat_config, tsv_path=None, out_dir=None, out_path=None, trim=False,
+                     min_read_length=0, nobatch=False, filter_barcodes=False, batch_size=4000, comm=None, shards=None):
+    """This rank's share of ONE file: its whole batches through the native file loop, outputs to `shard_paths(...)`, histograms
+    summed over the ranks when a communicator is given (any object with allreduce(values, op) -- native.NativeComm, a stub).
+    Returns (barcode counts, adapter counts, n_none, n_adapter_none, stats) with GLOBAL counts when `comm` is given.  The caller
+    runs `merge_shards` on one rank afterwards."""
+    import numpy as np
+    from . import native
+    layouts = detector.layouts
+    if shards is None:
+        shards, _, _ = file_shards(reads_fq, world_size, batch_size)
+    begin, end = shards[rank]
+    one_kit = len(set(l.kit for l in layouts)) == 1
+    kit_auto = (not nobatch) and not one_kit
+    kit = detector._native_kit(layouts, qcat_config, native.ENDS_BOTH)
+    dual = detector._native_mode == "dual"
+    sinks = []
+
+    def fd_of(p):
+        fh = open(shard_paths(p, rank), "wb")
+        sinks.append(fh)
+        return fh.fileno()
+    my_dir = None
+    if out_dir:
+        my_dir = shard_paths(out_dir, rank)
+        os.makedirs(my_dir, exist_ok=True)
+    try:
+        if end > begin:
+            bc, ad, n_none, n_ad_none, stats = native.FastqFile.demux_stream(
+                reads_fq, detector._context(), kit, layouts, dual, batch_size=batch_size, kit_auto=kit_auto, trim=trim,
+                min_read_length=min_read_length, tsv_fd=fd_of(tsv_path) if tsv_path else None,
+                out_fd=fd_of(out_path) if (out_path and not out_dir and not tsv_path) else None, out_dir=my_dir,
+                filter_barcodes=bool(filter_barcodes) and not nobatch, byte_range=(begin, end))
+        else:                                        # more ranks than batches: an empty shard (its outputs exist and are empty)
+            n_t = len(layouts)
+            w0 = max(1, max(len(l.get_barcode_set(0) or ()) for l in layouts))
+            w1 = max(1, max(len(l.get_barcode_set(1) or ()) for l in layouts)) if dual else 1
+            bc, ad, n_none, n_ad_none = np.zeros((n_t, w0, w1), dtype=np.int64), np.zeros(n_t, dtype=np.int64), 0, 0
+            stats = {"n_reads": 0, "n_skipped": 0, "file_bytes": 0, "parse_s": 0.0, "scan_s": 0.0, "write_s": 0.0, "total_s": 0.0,
+                     "next_offset": begin, "incomplete": 0, "segments": 0}
+            if tsv_path:
+                fd_of(tsv_path)
+            elif out_path and not out_dir:
+                fd_of(out_path)
+    finally:
+        for fh in sinks:
+            fh.close()
+    if comm is not None and world_size > 1:
+        flat = np.concatenate([bc.reshape(-1), ad.reshape(-1), [n_none, n_ad_none, stats["n_reads"], stats["n_skipped"]]]).astype(np.float64)
+        tot = np.asarray(comm.allreduce(flat.tolist(), native.REDUCE_SUM), dtype=np.float64)       # (exact: counts below 2^53)
+        nb, na = bc.size, ad.size
+        bc = np.rint(tot[:nb]).astype(np.int64).reshape(bc.shape)
+        ad = np.rint(tot[nb:nb + na]).astype(np.int64)
+        n_none, n_ad_none = int(round(tot[nb + na])), int(round(tot[nb + na + 1]))
+        stats = dict(stats, n_reads_total=int(round(tot[nb + na + 2])), n_skipped_total=int(round(tot[nb + na + 3])))
+    return bc, ad, n_none, n_ad_none, stats
+
+
+def merge_shards(path, world_size, is_dir=False, keep=False):
+    """string the ranks' shards of `path` together in rank order (one rank calls this after all are done: the result is the
+    one-rank output byte for byte).  Directories: per file name, in rank order.  The bytes move inside the kernel
+    (copy_file_range where the file system has it)."""
+    import shutil
+    if is_dir:
+        os.makedirs(path, exist_ok=True)
+        names = []
+        for r in range(world_size):
+            d = shard_paths(path, r)
+            if os.path.isdir(d):
+                for n in sorted(os.listdir(d)):
+                    if n not in names:
+                        names.append(n)
+        for n in names:
+            with open(os.path.join(path, n), "wb") as dst:
+                for r in range(world_size):
+                    src_path = os.path.join(shard_paths(path, r), n)
+                    if os.path.exists(src_path):
+                        with open(src_path, "rb") as src:
+                            shutil.copyfileobj(src, dst, 1 << 24)
+        if not keep:
+            for r in range(world_size):
+                shutil.rmtree(shard_paths(path, r), ignore_errors=True)
+        return
+    with open(path, "wb") as dst:
+        for r in range(world_size):
+            sp = shard_paths(path, r)
+            if os.path.exists(sp):
+                with open(sp, "rb") as src:
+                    shutil.copyfileobj(src, dst, 1 << 24)
+                if not keep:
+                    os.unlink(sp)

@@ -168,6 +168,10 @@ def test_rehearsal_of_eight_ranks_on_one_device():
     assert line["cpu_baseline"]["value"] > 0 and line["parity"]["mismatches_vs_oracle"] == 0
     hi = line["host_inclusive"]
     assert hi["value"] > 0 and hi["reads_per_gpu"] == 1000000
+    # round 6: ONE file over the eight ranks (whole batches per rank, a TSV shard each, histograms all-reduced, shards merged)
+    fq = hi["from_fastq"]
+    assert "error" not in fq, fq
+    assert fq["ranks"] == 8 and fq["reads"] == 1000000 and fq["rows_and_counts_complete"] is True and len(fq["shards_bytes"]) == 8
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     import bench
