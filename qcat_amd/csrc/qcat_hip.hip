@@ -73,17 +73,20 @@ std::atomic<int64_t> g_qcat_opt[QO_COUNT];
 static const char* const g_qcat_opt_name[QO_COUNT] = {
 #define X(N, D) #N,
     QCAT_OPTION_LIST(X)
+    QCAT_AB_OPTION_LIST(X)
 #undef X
 };
 static const char* const g_qcat_opt_doc[QO_COUNT] = {
 #define X(N, D) D,
     QCAT_OPTION_LIST(X)
+    QCAT_AB_OPTION_LIST(X)
 #undef X
 };
 static void qcat_options_from_env() {
     for (int i = 0; i < QO_COUNT; ++i) {
         const std::string env = std::string("QCAT_HIP_") + g_qcat_opt_name[i];
-        const char* e = getenv(env.c_str());                        // (the library's only look at QCAT_HIP_* switches: once, here)
+        const char* e = i < QO_SETTABLE ? getenv(env.c_str()) : nullptr;     // (the library's only look at QCAT_HIP_* switches: once, here;
+                                                                             //  the A/B switches of dropped variants: -DQCAT_AB builds only)
         g_qcat_opt[i].store(e ? (*e ? (int64_t)atoll(e) : 1) : QOPT_UNSET, std::memory_order_relaxed);
     }
 }
@@ -95,12 +98,12 @@ static struct QcatOptInit { QcatOptInit() { qcat_options_from_env(); } } g_qcat_
 static int qcat_opt_index(const char* name) {
     if (!name) return -1;
     if (strncmp(name, "QCAT_HIP_", 9) == 0) name += 9;
-    for (int i = 0; i < QO_COUNT; ++i) if (strcmp(name, g_qcat_opt_name[i]) == 0) return i;
+    for (int i = 0; i < QO_SETTABLE; ++i) if (strcmp(name, g_qcat_opt_name[i]) == 0) return i;
     return -1;
 }
-extern "C" int qcat_option_count(void) { return QO_COUNT; }
-extern "C" const char* qcat_option_name(int i) { return i >= 0 && i < QO_COUNT ? g_qcat_opt_name[i] : nullptr; }
-extern "C" const char* qcat_option_doc(int i) { return i >= 0 && i < QO_COUNT ? g_qcat_opt_doc[i] : nullptr; }
+extern "C" int qcat_option_count(void) { return QO_SETTABLE; }
+extern "C" const char* qcat_option_name(int i) { return i >= 0 && i < QO_SETTABLE ? g_qcat_opt_name[i] : nullptr; }
+extern "C" const char* qcat_option_doc(int i) { return i >= 0 && i < QO_SETTABLE ? g_qcat_opt_doc[i] : nullptr; }
 extern "C" void qcat_reset_options(void) { qcat_options_from_env(); qk::g_alloc_gen.fetch_add(1); }
 extern "C" int qcat_set_option(const char* name, int64_t value) {
     const int i = qcat_opt_index(name);
