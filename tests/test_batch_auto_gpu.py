@@ -143,12 +143,15 @@ def test_one_pass_is_cheaper_than_two_calls():
     bases, offsets = native.pack_reads(reads)
     det._context().scan_auto(kit, bases, offsets)
     _two_pass(det, reads[:100], cfg)                          # warm both routes (kit upload, buffers)
-    t0 = time.perf_counter(); det._context().scan_auto(kit, bases, offsets); t1 = time.perf_counter()
-    votes = det._context().detect_kit(kit, bases, offsets)
     sub = det._native_kit(det.get_adapters("PBC096"), cfg, native.ENDS_BOTH)
-    det._context().scan(sub, bases, offsets); t2 = time.perf_counter()
+    one, two = [], []
+    for _ in range(4):                                         # (the fastest of four of each: one run is at the mercy of the box)
+        t0 = time.perf_counter(); det._context().scan_auto(kit, bases, offsets); t1 = time.perf_counter()
+        votes = det._context().detect_kit(kit, bases, offsets)
+        det._context().scan(sub, bases, offsets); t2 = time.perf_counter()
+        one.append(t1 - t0); two.append(t2 - t1)
     assert votes[0].sum() == len(reads)
-    assert (t1 - t0) < (t2 - t1), (t1 - t0, t2 - t1)
+    assert min(one) < min(two), (one, two)
 
 
 def test_reads_handed_over_as_pointers_give_the_same_dicts(monkeypatch):
