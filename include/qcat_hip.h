@@ -527,6 +527,11 @@ int  qcat_fastq_demux(qcat_fastq* f, qcat_ctx* ctx, const qcat_kit* kit, const q
  * filter_barcodes).  Kits created with scan_middle_adapter (--detect-middle, scanner_base.py:593-595) upload whole reads.
  * Instead of one record per read the caller gets what the driver keeps: the histograms of the reads that passed the
  * minimum-length filter, as counts per (template, barcode of set 0[, barcode of set 1]) and per template.
+ * Round 6: a segment whose records are not all plain -- wrapped sequence / quality lines, \r\n line ends, blank lines, trailing
+ * blanks -- is rewritten as plain records by the reference's parsers' rules (Biopython's FastqGeneralIterator /
+ * SimpleFastaParser, qcat/cli.py:235-306) on one thread and handled like any other; "not plain" below means what even those
+ * rules reject or what the caller's parser has to report itself (quality and sequence of different lengths, captions that
+ * differ, blanks inside a sequence, an empty sequence, bytes outside ASCII, a lone \r).
  * A record that is not a plain four-line FASTQ / two-line FASTA record: in the first segment QCAT_ERR_UNSUPPORTED before
  * anything is written (as qcat_fastq_open); later the call ends in front of that record's segment -- a batch boundary --
  * with stats->incomplete = 1, stats->next_offset = the file offset of the segment's first record and stats->n_reads = the
