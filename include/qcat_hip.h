@@ -497,6 +497,14 @@ typedef struct qcat_demux_opts {
      * (qcat/cli.py:500-513: vote and filter are per batch); the outputs are the shard's own (the caller gives every rank its own
      * descriptors / directory and strings the shards together in rank order), stats->next_offset stays a file offset. */
     uint64_t range_begin, range_end;
+    /* ABI 6: the input as a DESCRIPTOR instead of a path (`path` may be NULL) -- the driver's `cat *.fastq | qcat -b out`
+     * (README.md:104; qcat/cli.py:256-257 reads sys.stdin, assumed FASTQ).  input_fd - 1 is the descriptor (0 keeps the field's
+     * zero default meaning "the path"): a regular file is handled like a path; anything else (a pipe) is read sequentially in
+     * segments.  A stream cannot be handed back by offset: when the loop ends in front of a segment it does not take (see
+     * below) the bytes already read and not handled are written to rest_fd - 1 (a descriptor of the caller, e.g. an unlinked
+     * temporary file; required with a stream), stats->incomplete = 1, and the caller's parser reads that file and then the
+     * rest of the stream.  A stream never answers QCAT_ERR_UNSUPPORTED for its content (its first bytes are consumed too). */
+    int32_t input_fd, rest_fd;
 } qcat_demux_opts;
 typedef struct qcat_demux_stats {
     uint64_t n_reads, n_skipped, file_bytes;

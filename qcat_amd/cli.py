@@ -14,6 +14,7 @@ text, of that file; all alignment work happens in one native call per batch.
 from __future__ import print_function
 
 import argparse
+import io
 import itertools
 import logging
 import os
@@ -175,11 +176,35 @@ def _fasta_records(handle):
         yield title, "".join(chunks).replace(" ", "").replace("\r", "")
 
 
-def iter_fastx(reads_fx, fastq, batchsize, offset=0):
+class _ChainedRaw(io.RawIOBase):
+    """the bytes of several binary streams one after the other (what the native loop read from stdin and did not handle, then
+    stdin itself)"""
+
+    def __init__(self, parts):
+        io.RawIOBase.__init__(self)
+        self.parts = list(parts)
+
+    def readable(self):
+        return True
+
+    def readinto(self, b):
+        while self.parts:
+            data = self.parts[0].read(len(b))
+            if data:
+                b[:len(data)] = data
+                return len(data)
+            self.parts.pop(0)
+        return 0
+
+
+def iter_fastx(reads_fx, fastq, batchsize, offset=0, handle=None):
     """Yield (names, comments, seqs, quals) lists of at most ``batchsize`` reads; ``offset``: the byte of the file to start
-    at (a record start: where the native loop handed the file back, ``_native_demux``)."""
+    at (a record start: where the native loop handed the file back, ``_native_demux``); ``handle``: a text stream to read
+    instead (stdin behind what the native loop gave back)."""
     names, comments, seqs, quals = [], [], [], []
-    if reads_fx and offset:
+    if handle is not None:
+        pass
+    elif reads_fx and offset:
         # a BYTE offset: seek the binary file, then wrap it -- a text handle only defines seek() for cookies of its own tell()
         # (ADVICE r5: an arbitrary offset works by accident while the decoder is stateless)
         import io
@@ -205,7 +230,7 @@ def iter_fastx(reads_fx, fastq, batchsize, offset=0):
             logging.error(str(e))
             sys.exit(1)
     finally:
-        if reads_fx:
+        if reads_fx and handle is not sys.stdin:
             handle.close()
     if names:
         yield names, comments, seqs, quals
@@ -310,12 +335,23 @@ def _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_
     tsv_sink = _FdSink(tsv_stream) if tsv else None
     out_sink = _FdSink(stream) if (not out and not tsv) else None
     dual = detector._native_mode == "dual"
+    # no file name: the driver's stdin (`cat *.fastq | qcat -b out`, README.md:104 of the reference) -- the descriptor itself; what
+    # the native loop reads from a pipe and does not handle comes back in `rest`, in front of the rest of the stream
+    stdin_fd, rest = None, None
+    if not reads_fq:
+        import tempfile
+        try:
+            stdin_fd = sys.stdin.buffer.fileno()
+        except (AttributeError, ValueError, io.UnsupportedOperation):
+            return None                                  # (a replaced sys.stdin without a descriptor: the Python loop reads it)
+        rest = tempfile.TemporaryFile()
     try:
         bc, ad, n_none, n_ad_none, stats = native.FastqFile.demux_stream(
-            reads_fq, detector._context(), kit, layouts, dual, batch_size=BATCH_SIZE, kit_auto=kit_auto, trim=trim,
+            reads_fq if reads_fq else None, detector._context(), kit, layouts, dual, batch_size=BATCH_SIZE, kit_auto=kit_auto, trim=trim,
             min_read_length=min_read_length, tsv_fd=tsv_sink.fd if tsv_sink else None, out_fd=out_sink.fd if out_sink else None,
             out_dir=out if out else None, filter_barcodes=bool(filter_barcodes) and not nobatch,
-            segment_bytes=int(os.environ.get("QCAT_AMD_SEGMENT_BYTES", "0") or 0))
+            segment_bytes=int(os.environ.get("QCAT_AMD_SEGMENT_BYTES", "0") or 0),
+            input_fd=stdin_fd, rest_fd=rest.fileno() if rest is not None else None)
     except native.FastqFile.Unsupported:
         return None
     for sink in (tsv_sink, out_sink):
@@ -339,7 +375,14 @@ def _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_
         else:
             name = first.name
         barcode_dist[name] = barcode_dist.get(name, 0) + int(bc[t, i, j])
-    return barcode_dist, adapter_dist, stats["n_reads"], stats["n_skipped"], (stats["next_offset"] if stats["incomplete"] else None)
+    resume = stats["next_offset"] if stats["incomplete"] else None
+    if rest is not None:
+        if stats["incomplete"]:
+            rest.seek(0)
+            resume = io.TextIOWrapper(_ChainedRaw([rest, sys.stdin.buffer]))      # (a handle instead of an offset)
+        else:
+            rest.close()
+    return barcode_dist, adapter_dist, stats["n_reads"], stats["n_skipped"], resume
 
 
 def qcat_cli(reads_fq, kit, mode, nobatch, out, min_qual, tsv, output, threads, trim, adapter_yaml, quiet,
@@ -354,7 +397,7 @@ def qcat_cli(reads_fq, kit, mode, nobatch, out, min_qual, tsv, output, threads, 
     fastq = is_fastq(reads_fq)
     stream = open(output, "w") if output else sys.stdout
     native_done = None
-    if reads_fq and mode in ("epi2me", "dual") and not os.environ.get("QCAT_AMD_NO_NATIVE_FASTQ"):
+    if mode in ("epi2me", "dual") and not os.environ.get("QCAT_AMD_NO_NATIVE_FASTQ"):
         # plain four-line FASTQ files and plain two-line FASTA files go through the native ingest / egress
         # (qcat_fastq_demux_stream): same outputs, no Python string per read, --detect-middle and --filter-barcodes included;
         # anything else (stdin, wrapped or odd records, simple mode) stays on -- or comes back to -- the loop below
@@ -372,8 +415,10 @@ def qcat_cli(reads_fq, kit, mode, nobatch, out, min_qual, tsv, output, threads, 
         if output:
             stream.close()
         return barcode_dist, adapter_dist, total_reads, skipped_reads
-    outputs = _Outputs(out, stream, fastq, append=bool(resume))
-    for names, comments, seqs, quals in iter_fastx(reads_fq, fastq, 1 if nobatch else BATCH_SIZE, offset=resume or 0):
+    resume_handle = resume if (resume is not None and not isinstance(resume, int)) else None
+    outputs = _Outputs(out, stream, fastq, append=(resume is not None and native_done is not None and total_reads > 0))
+    for names, comments, seqs, quals in iter_fastx(reads_fq, fastq, 1 if nobatch else BATCH_SIZE, offset=0 if resume_handle else (resume or 0),
+                                                   handle=resume_handle):
         if nobatch:
             results = [detector.detect_barcode(read_sequence=seqs[0], read_qualities=quals[0], qcat_config=qcat_config)]
         else:

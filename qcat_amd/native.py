@@ -103,7 +103,7 @@ class DemuxOpts(C.Structure):
                 ("kit_name", C.POINTER(C.c_char_p)), ("bc_name", C.POINTER(C.POINTER(C.c_char_p))),
                 ("bc_id", C.POINTER(C.POINTER(C.c_int32))), ("bc2_id", C.POINTER(C.POINTER(C.c_int32))),
                 ("filter_barcodes", C.c_int32), ("stream_reader", C.c_int32), ("segment_bytes", C.c_uint64),
-                ("range_begin", C.c_uint64), ("range_end", C.c_uint64)]
+                ("range_begin", C.c_uint64), ("range_end", C.c_uint64), ("input_fd", C.c_int32), ("rest_fd", C.c_int32)]
 
 
 class DemuxStats(C.Structure):
@@ -713,7 +713,7 @@ class FastqFile(object):
 
     @staticmethod
     def _demux_opts(layouts, dual, batch_size, kit_auto, trim, min_read_length, tsv_fd, out_fd, out_dir, filter_barcodes, segment_bytes, reader=0,
-                    byte_range=None):
+                    byte_range=None, input_fd=None, rest_fd=None):
         """a qcat_demux_opts and the buffers it points to"""
         n_t = len(layouts)
         keep = []
@@ -739,7 +739,8 @@ class FastqFile(object):
                       kit_name=C.cast(kit_names, C.POINTER(C.c_char_p)), bc_name=C.cast(bc_name, C.POINTER(C.POINTER(C.c_char_p))),
                       bc_id=C.cast(bc_id, C.POINTER(C.POINTER(C.c_int32))), bc2_id=C.cast(bc2_id, C.POINTER(C.POINTER(C.c_int32))),
                       filter_barcodes=1 if filter_barcodes else 0, stream_reader=int(reader), segment_bytes=int(segment_bytes or 0),
-                      range_begin=int(byte_range[0]) if byte_range else 0, range_end=int(byte_range[1]) if byte_range else 0)
+                      range_begin=int(byte_range[0]) if byte_range else 0, range_end=int(byte_range[1]) if byte_range else 0,
+                      input_fd=0 if input_fd is None else int(input_fd) + 1, rest_fd=0 if rest_fd is None else int(rest_fd) + 1)
         return o, keep
 
     def demux(self, ctx, kit, layouts, dual, batch_size=4000, kit_auto=False, trim=False, min_read_length=0,
@@ -788,16 +789,19 @@ class FastqFile(object):
 
     @staticmethod
     def demux_stream(path, ctx, kit, layouts, dual, batch_size=4000, kit_auto=False, trim=False, min_read_length=0,
-                     tsv_fd=None, out_fd=None, out_dir=None, filter_barcodes=False, segment_bytes=0, reader=0, byte_range=None):
+                     tsv_fd=None, out_fd=None, out_dir=None, filter_barcodes=False, segment_bytes=0, reader=0, byte_range=None,
+                     input_fd=None, rest_fd=None):
         """qcat_fastq_demux_stream: the file in segments through read | scan | write, host memory independent of its size.
         ``byte_range`` = (begin, end): a rank's shard of the file, both record starts (``batch_offsets``; end 0: the file's end).
+        ``input_fd`` (``path`` None): the input as a descriptor -- the driver's stdin; a pipe is read in order, and when the loop
+        ends early (``stats["incomplete"]``) the bytes it had read and not handled are in ``rest_fd`` (a file of the caller's).
         Returns (barcode counts [template][barcode][second barcode], adapter counts [template], reads without a barcode,
         reads without an adapter, stats dict); ``stats["incomplete"]``: the loop ended at ``stats["next_offset"]`` in front of
         a record that is not plain -- the caller's own parser carries on from there.  Raises ``Unsupported`` when that is the
         case for the very first segment (nothing has been written)."""
         hip = HipLibrary.get()
         o, _keep = FastqFile._demux_opts(layouts, dual, batch_size, kit_auto, trim, min_read_length, tsv_fd, out_fd, out_dir,
-                                         filter_barcodes, segment_bytes, reader, byte_range)
+                                         filter_barcodes, segment_bytes, reader, byte_range, input_fd, rest_fd)
         n_t = len(layouts)
         w0 = max(1, max(len(l.get_barcode_set(0) or ()) for l in layouts))
         w1 = max(1, max(len(l.get_barcode_set(1) or ()) for l in layouts)) if dual else 1
@@ -805,7 +809,7 @@ class FastqFile(object):
         adapter = np.zeros(n_t, dtype=np.int64)
         h = DemuxHist(w0=w0, w1=w1, barcode=barcode.ctypes.data_as(C.POINTER(C.c_int64)), adapter=adapter.ctypes.data_as(C.POINTER(C.c_int64)))
         st = DemuxStats()
-        rc = hip.lib.qcat_fastq_demux_stream(os.fsencode(path), ctx.handle, kit.handle, C.byref(o), C.byref(h), C.byref(st))
+        rc = hip.lib.qcat_fastq_demux_stream(os.fsencode(path) if path is not None else None, ctx.handle, kit.handle, C.byref(o), C.byref(h), C.byref(st))
         if rc == -2 and int(st.segments) == 0 and int(st.n_reads) == 0:
             # "not for the native loop" is only an answer while NOTHING has been written: the caller then parses the file
             # itself from offset 0.  An UNSUPPORTED behind written segments (a scan call refused later in the file) is an

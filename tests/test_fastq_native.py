@@ -159,18 +159,26 @@ def test_streamed_fasta_and_the_hand_back_at_a_record_that_is_not_plain(tmp_path
         fh.write("".join(t + "\n" + s + "\n" for t, s in recs))
     n, nb, off, _ = native.FastqFile.stream_count(path, 5000, 50)
     assert (n, nb, off) == (2000, sum(len(s) for _t, s in recs), os.path.getsize(path))
-    # a wrapped record in the middle: the rounds end in front of ITS segment, at a batch boundary, and say where
+    # round 6: a WRAPPED record in the middle is taken (its segment is rewritten as plain records, tests/test_fastq_wrapped.py)
     text = "".join("@q%d\n%s\n+\n%s\n" % (i, "ACGT" * 20, "I" * 80) for i in range(1000))
-    bad = text + "@wrapped\nACGT\nACGT\n+\nIIIIIIII\n" + "".join("@z%d\nAC\n+\nII\n" % i for i in range(10))
+    tail = "".join("@z%d\nAC\n+\nII\n" % i for i in range(10))
     path = str(tmp_path / "wrapped_later.fastq")
+    with open(path, "w") as fh:
+        fh.write(text + "@wrapped\nACGT\nACGT\n+\nIIIIIIII\n" + tail)
+    n, nb, off, _ = native.FastqFile.stream_count(path, 10000, 10)
+    assert (n, nb, off) == (1011, 80 * 1000 + 8 + 20, os.path.getsize(path))
+    # a record the Python parser has to report itself (the captions differ) in the middle: the rounds end in front of ITS
+    # segment, at a batch boundary, and say where
+    bad = text + "@odd\nACGT\n+other\nIIII\n" + tail
+    path = str(tmp_path / "odd_later.fastq")
     with open(path, "w") as fh:
         fh.write(bad)
     n, _nb, off, _ = native.FastqFile.stream_count(path, 10000, 10)
     assert 0 < n < 1000 and n % 10 == 0 and bad[off:off + 2] == "@q" and bad[:off].count("\n") == 4 * n
     # ... and in the very first segment nothing is handed out at all
-    path = str(tmp_path / "wrapped_first.fastq")
+    path = str(tmp_path / "odd_first.fastq")
     with open(path, "w") as fh:
-        fh.write("@wrapped\nACGT\nACGT\n+\nIIIIIIII\n" + text)
+        fh.write("@odd\nACGT\n+other\nIIII\n" + text)
     with pytest.raises(native.FastqFile.Unsupported):
         native.FastqFile.stream_count(path, 10000, 10)
     empty = str(tmp_path / "empty.fastq")

@@ -74,18 +74,19 @@ def test_what_the_python_parser_must_report_itself_is_left_to_it(tmp_path):
         "length": "@a\n%s\n+\n%s\n" % (reads[0], "I" * (len(reads[0]) - 1)),                 # lengths differ
         "caption": "@a\n%s\n+b\n%s\n" % (reads[0], "I" * len(reads[0])),                      # captions differ
         "blank_in_seq": "@a\n%s %s\n+\n%s\n" % (reads[0][:10], reads[0][10:], "I" * len(reads[0])),
-        "utf8": "@a \xc3\xa9\n%s\n+\n%s\n" % (reads[0], "I" * len(reads[0])),
+        "form_feed": "@a\n%s\x0c%s\n+\n%sI\n" % (reads[0][:10], reads[0][10:], "I" * len(reads[0])),
+        "utf8": b"@a \xc3\xa9\n".decode("latin-1") + "%s\n+\n%s\n" % (reads[0], "I" * len(reads[0])),
         "lone_cr": "@a\n%s\r%s\n+\n%s\n" % (reads[0][:10], reads[0][10:], "I" * len(reads[0])),
     }
     for name, text in cases.items():
         p = str(tmp_path / (name + ".fastq"))
         good = "".join("@g%d\n%s\n+\n%s\n" % (i, r, "I" * len(r)) for i, r in enumerate(reads))
-        with open(p, "w", newline="") as fh:
+        with open(p, "w", newline="", encoding="latin-1") as fh:
             fh.write(good + text)
         # small segments: the good records in front are handled, the loop stops at a batch / segment boundary before the odd one
         got = native.FastqFile.stream_count(p, segment_bytes=1 << 14, batch_size=0)
         assert got[2] <= len(good) and got[0] <= len(reads), (name, got)
-        with open(p, "w", newline="") as fh:
+        with open(p, "w", newline="", encoding="latin-1") as fh:
             fh.write(text)
         with pytest.raises(native.FastqFile.Unsupported):
             native.FastqFile.stream_count(p)
@@ -124,3 +125,63 @@ def test_driver_outputs_on_wrapped_files(tmp_path, form, monkeypatch):
     for f in out["native"][1]:
         assert out["native"][1][f] == out["python"][1][f], f
     assert out["native"][3] == out["python"][3] and out["native"][3].count("\n") == len(reads)
+
+
+def _run_cli(args, stdin_bytes=None, stdin_path=None, env=None):
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); from qcat_amd import cli; cli.main(sys.argv[1:])" % helpers.ROOT if hasattr(helpers, "ROOT") else None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); from qcat_amd import cli; cli.main(sys.argv[1:])" % root
+    e = dict(os.environ)
+    e.update(env or {})
+    kw = {}
+    if stdin_path:
+        kw["stdin"] = open(stdin_path, "rb")
+    p = subprocess.run([sys.executable, "-c", code] + args, input=stdin_bytes, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600, **kw)
+    if stdin_path:
+        kw["stdin"].close()
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return p.stdout, p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["plain", "fastq80", "odd_record_in_the_middle"])
+def test_stdin_takes_the_native_loop(tmp_path, form):
+    """`cat reads.fastq | qcat -b out --trim` (README.md:104 of the reference): a pipe on the native loop, against the Python loop
+    on the same bytes; a record only the Python parser takes in the middle of the stream (blank inside the sequence is an error
+    -- here: a record whose caption differs is an error too, so the odd one is a tab inside a title, which is NOT plain for the
+    fast splitter but fine for both parsers) hands the rest of the stream back without losing a byte."""
+    rng = random.Random(4)
+    det = scanner.factory(kit="PBC096")
+    reads = synth.synth_batch(12000, 22, det.layouts, 1, 0, error_rate=0.07, insert_len=250)
+    p = str(tmp_path / "r.fastq")
+    if form == "odd_record_in_the_middle":
+        with open(p, "w") as fh:
+            for i, r in enumerate(reads):
+                q = "I" * len(r)
+                if i == 7000:
+                    fh.write("@read%d\tx\n%s\x0c%s\n+\n%sI\n" % (i, r[:10], r[10:], q))     # a form feed inside the sequence: Biopython keeps it, the native loop leaves it to the Python parser
+                else:
+                    fh.write("@read%d ch=%d\n%s\n+\n%s\n" % (i, i % 512, r, q))
+    else:
+        _write(p, "fastq_mixed" if form == "fastq80" else "fastq_plus_title", reads, rng)
+    data = open(p, "rb").read()
+    seg = {"QCAT_AMD_SEGMENT_BYTES": str(1 << 20)}
+    out = {}
+    for route, env in (("native", seg), ("python", dict(seg, QCAT_AMD_NO_NATIVE_FASTQ="1"))):
+        d = str(tmp_path / ("bc_" + route))
+        _run_cli(["-b", d, "--trim", "-k", "PBC096", "--min-read-length", "50"], stdin_bytes=data, env=env)
+        files = {}
+        for f in sorted(os.listdir(d)):
+            with open(os.path.join(d, f), "rb") as fh:
+                files[f] = fh.read()
+        tsv, err = _run_cli(["--tsv", "-k", "PBC096", "--min-read-length", "0"], stdin_bytes=data, env=env)
+        redirected, _ = _run_cli(["--tsv", "-k", "PBC096", "--min-read-length", "0"], stdin_path=p, env=env)     # `qcat < file`
+        assert redirected == tsv
+        out[route] = (files, tsv, [l for l in err.decode().splitlines() if "barcode" in l or "reads" in l])
+    assert out["native"][0].keys() == out["python"][0].keys() and len(out["native"][0]) > 20
+    for f in out["native"][0]:
+        assert out["native"][0][f] == out["python"][0][f], f
+    assert out["native"][1] == out["python"][1] and out["native"][1].count(b"\n") == len(reads) + 1
+    assert out["native"][2] == out["python"][2]
