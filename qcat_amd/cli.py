@@ -378,6 +378,9 @@ def _native_demux(detector, reads_fq, nobatch, out, tsv, stream, trim, min_read_
     resume = stats["next_offset"] if stats["incomplete"] else None
     if rest is not None:
         if stats["incomplete"]:
+            import stat
+            if stat.S_ISREG(os.fstat(stdin_fd).st_mode):
+                os.lseek(stdin_fd, stats["next_offset"], os.SEEK_SET)     # `qcat < file`: read by offset, the descriptor has not moved
             rest.seek(0)
             resume = io.TextIOWrapper(_ChainedRaw([rest, sys.stdin.buffer]))      # (a handle instead of an offset)
         else:

@@ -11,7 +11,7 @@ import pytest
 
 import helpers  # noqa: F401
 import synth
-from qcat_amd import cli, native, scanner
+from qcat_amd import cli, config, native, scanner
 
 
 def _reads(n, seed=3):
@@ -110,7 +110,7 @@ def test_driver_outputs_on_wrapped_files(tmp_path, form, monkeypatch):
         buf = io.StringIO()
         dist = cli.qcat_cli(reads_fq=p, kit="PBC096", mode="epi2me", nobatch=False, out=d, min_qual=None, tsv=False, output=None,
                             threads=1, trim=True, adapter_yaml=None, quiet=True, filter_barcodes=False, middle_adapter=False,
-                            min_read_length=50, qcat_config=None, tsv_stream=buf)
+                            min_read_length=50, qcat_config=config.get_default_config(), tsv_stream=buf)
         files = {}
         for f in sorted(os.listdir(d)):
             with open(os.path.join(d, f), "rb") as fh:
@@ -118,13 +118,13 @@ def test_driver_outputs_on_wrapped_files(tmp_path, form, monkeypatch):
         tsv = io.StringIO()
         dist2 = cli.qcat_cli(reads_fq=p, kit="PBC096", mode="epi2me", nobatch=False, out=None, min_qual=None, tsv=True, output=None,
                              threads=1, trim=False, adapter_yaml=None, quiet=True, filter_barcodes=False, middle_adapter=False,
-                             min_read_length=0, qcat_config=None, tsv_stream=tsv)
+                             min_read_length=0, qcat_config=config.get_default_config(), tsv_stream=tsv)
         out[route] = (dist, files, dist2, tsv.getvalue())
     assert out["native"][0] == out["python"][0] and out["native"][2] == out["python"][2]
     assert out["native"][1].keys() == out["python"][1].keys() and len(out["native"][1]) > 20
     for f in out["native"][1]:
         assert out["native"][1][f] == out["python"][1][f], f
-    assert out["native"][3] == out["python"][3] and out["native"][3].count("\n") == len(reads)
+    assert out["native"][3] == out["python"][3] and out["native"][3].count("\n") == len(reads) + 1      # (the header line)
 
 
 def _run_cli(args, stdin_bytes=None, stdin_path=None, env=None):
