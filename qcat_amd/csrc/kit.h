@@ -27,7 +27,7 @@ constexpr int MAX_TARGET = QCAT_MAX_TARGET_LEN;
 constexpr int MAX_WIN = QCAT_MAX_WINDOW;
 constexpr int WIN_STRIDE = 160;          // bytes per packed code window (16-B aligned rows)
 constexpr int WIN2_WORDS = WIN_STRIDE / 16; // dwords of a window at two bits per code (k_pack_windows: win2)
-constexpr int BS_PAD_ROWS = 5;              // rows a region of the "short of nominal" class may miss (front padding of the bit-sliced barcode units)
+constexpr int BS_PAD_ROWS = 12;             // rows a region of the "short of nominal" class may miss (front padding of the bit-sliced barcode units)
 constexpr int WIN2_FRONT = 16;              // dwords of slack in front of the first window of the context's win2 buffer
 constexpr int RAW_NEVER = 1 << 20;       // "no raw score passes"
 constexpr int PADMAX = 8;                // most leading padding columns a width class may have

@@ -658,7 +658,7 @@ def test_bit_sliced_adapter_kernels_equal_the_binary16_kernels_and_the_oracle(mo
                                                    ("dual", None, 1, 0, False), ("epi2me", "NBD104/NBD114", 1, 0, False),
                                                    ("epi2me", "PBC096", 1, 0, True)])
 def test_bit_sliced_units_padded_at_the_front_for_regions_short_of_nominal(mode, kit, t5, t3, custom, monkeypatch):
-    """Round 5: a barcode region clipped by its window -- 1 .. 5 bases short of the nominal length (0.64 % of config 3's jobs, 2 %
+    """Round 5: a barcode region clipped by its window -- 1 .. BS_PAD_ROWS (12; round 5: 5) bases short of the nominal length (0.64 % of config 3's jobs, 2 %
     of its step on the binary16 kernels) -- shares the nominal units' row count: its alignment starts a few rows late and is
     held at the boundary state until then (csrc/bs_core.h: bs_hold / bs_keep).  Reads whose adapter starts within a few bases of
     the read's end, so that the region in front of the barcode runs out of the window (both ends; the first bases of some reads
@@ -672,7 +672,7 @@ def test_bit_sliced_units_padded_at_the_front_for_regions_short_of_nominal(mode,
     n = 9000
     reads = synth.synth_batch(n, 515, det.layouts, t5, t3, error_rate=0.06, lead_min=0, lead_max=8)
     for i in range(0, n, 7):
-        reads[i] = reads[i][(i % 5):len(reads[i]) - (i % 9)]     # windows that start / end inside the adapter's first bases
+        reads[i] = reads[i][(i % 13):len(reads[i]) - (i % 14)]     # windows that start / end inside the adapter's first bases (up to BS_PAD_ROWS and beyond)
     reads[3], reads[4] = "", "ACGT" * 30
     d = det.descriptor(qcat_config=cfg)
     want, want_cnt = oracle_lib.scan(d, reads, counts=True, threads=8)
