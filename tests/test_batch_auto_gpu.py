@@ -246,3 +246,33 @@ def test_several_batches_in_one_call_vote_one_by_one():
     # one batch only (batch_reads >= n): the plain call
     recs1, slots1 = ctx.scan_batches_auto_views(kit, native.read_views(reads[:1500]), 1500, 4000)
     assert len(slots1) == 1 and slots1[0] == slots[0] and np.array_equal(recs1, recs[:1500])
+
+
+@pytest.mark.parametrize("kit,n", [(None, 2500), ("NBD103/NBD104", 2500), ("RAB204", 900), (None, 20000)])
+def test_adapter_chains_of_a_small_batch_in_one_launch(kit, n, hip_options):
+    """Round 6: the static-letter adapter chains of a small batch -- nine launches for the twelve auto-detect templates -- leave as
+    ONE launch whose blockIdx.y picks the chain (csrc/static_generated.inc: k_adapter_multi).  Records, counts, every template's
+    raw score and end (the traces) and every barcode row: identical to launches of their own (QCAT_HIP_NO_ADAPTER_MULTI=1) and to
+    the oracle; 20 000 reads are beyond the switch and take their own launches either way."""
+    det = scanner.factory(kit=kit)
+    cfg = config.qcatConfig()
+    if kit is None:
+        reads = _mixed_batch(det, "PBC096", n, 5)
+    else:
+        reads = synth.synth_batch(n, 9, det.layouts, len(det.layouts) - 1, 0, error_rate=0.08, no_adapter_fraction=0.2)
+        reads[5], reads[6], reads[7] = "", "N" * 180, "ACGT" * 50
+    desc = det.descriptor(qcat_config=cfg)
+    bases, offsets = native.pack_reads(reads)
+    o_recs, o_cnt, o_traces, o_rows = oracle_lib.scan(desc, reads, counts=True, trace=True, rows=True, threads=8)
+    for variant in ("one launch", "launches of their own"):
+        hip_options(NO_ADAPTER_MULTI=None if variant == "one launch" else 1, NO_TINY=1)
+        cnt = np.zeros(desc.n_count_buckets, dtype=np.int64)
+        recs, traces, rows = native.NativeContext(0).scan(native.NativeKit(desc), bases, offsets, counts=cnt, trace=True, rows=True)
+        assert recs.tobytes() == o_recs.tobytes(), variant
+        assert np.array_equal(cnt, o_cnt), variant
+        for name in native.TRACE_DTYPE.names:
+            assert np.array_equal(traces[name], o_traces[name]), (variant, name)
+        assert np.array_equal(rows, o_rows), variant
+        cnt2 = np.zeros(desc.n_count_buckets, dtype=np.int64)             # (and without the traces: the records-only kernels)
+        assert native.NativeContext(0).scan(native.NativeKit(desc), bases, offsets, counts=cnt2).tobytes() == o_recs.tobytes(), variant
+        assert np.array_equal(cnt2, o_cnt), variant

@@ -375,6 +375,29 @@ def render():
             fh.write("    case %d: hipLaunchKernelGGL((k_adapter_fused2<%d, %d, %d, QAF_%d>), grid, dim3(PK_WAVES * 64), 0, stream, a); break;\n"
                      % (fid, u, len(sa), len(sb), fid))
         fh.write("    default: break;\n    }\n}\n\n")
+        # ---- every chain of a small batch in one launch ------------------------------------------
+        fh.write("// every static-letter adapter chain of a SMALL batch in one launch (packed_host.inc: packed_adapter): blockIdx.y = the unit --\n"
+                 "// a template or a fused pair.  The units of such a batch are latency chains (one wave per SIMD, 50-110 us each for the\n"
+                 "// 4000 reads of the reference driver's call), and launches of their own are serialised by the runtime's four hardware queues.\n"
+                 "__global__ void __launch_bounds__(PK_WAVES * 64, 2)\n"
+                 "k_adapter_multi(StaticAdapterMulti m) {\n"
+                 "    __shared__ uint8_t qbuf[PK_ROWS * 64];\n"
+                 "    __shared__ uint16_t slow_tbl[5 * 16];\n"
+                 "    const int i = blockIdx.y;\n"
+                 "    StaticAdapterArgs a = m.common;\n"
+                 "    a.bests = m.bests[i]; a.bests2 = m.bests2[i]; a.tpl = m.tpl[i]; a.tpl2 = m.tpl2[i];\n"
+                 "    const int kernel = m.kernel[i];\n"
+                 "    if (m.fused[i]) {\n"
+                 "        switch (kernel) {\n")
+        for fid, (sa, sb) in enumerate(fused):
+            u = len(os.path.commonprefix([sa, sb]))
+            fh.write("        case %d: adapter_fused2_core<%d, %d, %d, QAF_%d>(a, qbuf, slow_tbl); break;\n" % (fid, u, len(sa), len(sb), fid))
+        fh.write("        default: break;\n        }\n    } else {\n        switch (kernel) {\n")
+        for tid, seq in enumerate(templates):
+            fh.write("        case %d: adapter_static_core<%d, QAC_%d>(a, qbuf, slow_tbl); break;\n" % (tid, len(seq), tid))
+        fh.write("        default: break;\n        }\n    }\n}\n"
+                 "static inline void launch_adapter_multi(dim3 grid, hipStream_t stream, const StaticAdapterMulti& m) {\n"
+                 "    hipLaunchKernelGGL(k_adapter_multi, grid, dim3(PK_WAVES * 64), 0, stream, m);\n}\n\n")
         fh.write("// the same column chains over the read interior (--detect-middle, kernels_middle.inc)\n")
         fh.write("#ifdef QCAT_HAVE_MIDDLE_KERNELS\n")
         fh.write("static inline void launch_adapter_middle(int kernel, dim3 grid, hipStream_t stream, const MiddleAdapterArgs& a) {\n"
