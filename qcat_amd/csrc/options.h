@@ -19,6 +19,7 @@
     X(NO_STATIC, "1: no generated static-letter kernels (binary16 table kernels instead)") \
     X(NO_STATIC_ADAPTER, "1: the adapter templates on the table kernels") \
     X(NO_FUSED_ADAPTER, "1: the two templates of a kit as two launches instead of the fused kernel") \
+    X(NO_BARCODE_MULTI, "1: the static-letter barcode kernels of a small batch as launches of their own instead of one (k_barcode_multi)") \
     X(NO_ADAPTER_MULTI, "1: the static-letter adapter kernels of a small batch as launches of their own instead of one (k_adapter_multi)") \
     X(BARCODE_U16, "1 at kit creation: u16 lanes instead of exact-integer binary16 for the barcode tables") \
     X(NO_BITSLICE, "1: every barcode alignment on the binary16 kernels") \

@@ -253,7 +253,8 @@ def test_adapter_chains_of_a_small_batch_in_one_launch(kit, n, hip_options):
     """Round 6: the static-letter adapter chains of a small batch -- nine launches for the twelve auto-detect templates -- leave as
     ONE launch whose blockIdx.y picks the chain (csrc/static_generated.inc: k_adapter_multi).  Records, counts, every template's
     raw score and end (the traces) and every barcode row: identical to launches of their own (QCAT_HIP_NO_ADAPTER_MULTI=1) and to
-    the oracle; 20 000 reads are beyond the switch and take their own launches either way."""
+    the oracle; 20 000 reads are beyond the switch and take their own launches either way.  The same for the barcode groups
+    (k_barcode_multi, QCAT_HIP_NO_BARCODE_MULTI=1)."""
     det = scanner.factory(kit=kit)
     cfg = config.qcatConfig()
     if kit is None:
@@ -264,8 +265,9 @@ def test_adapter_chains_of_a_small_batch_in_one_launch(kit, n, hip_options):
     desc = det.descriptor(qcat_config=cfg)
     bases, offsets = native.pack_reads(reads)
     o_recs, o_cnt, o_traces, o_rows = oracle_lib.scan(desc, reads, counts=True, trace=True, rows=True, threads=8)
-    for variant in ("one launch", "launches of their own"):
-        hip_options(NO_ADAPTER_MULTI=None if variant == "one launch" else 1, NO_TINY=1)
+    for variant in ("one launch", "launches of their own", "barcode groups in launches of their own"):
+        hip_options(NO_ADAPTER_MULTI=1 if variant == "launches of their own" else None,
+                    NO_BARCODE_MULTI=None if variant == "one launch" else 1, NO_TINY=1)
         cnt = np.zeros(desc.n_count_buckets, dtype=np.int64)
         recs, traces, rows = native.NativeContext(0).scan(native.NativeKit(desc), bases, offsets, counts=cnt, trace=True, rows=True)
         assert recs.tobytes() == o_recs.tobytes(), variant

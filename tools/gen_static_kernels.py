@@ -297,6 +297,21 @@ def render():
         for kid in range(len(fams)):
             fh.write("    case %d: hipLaunchKernelGGL(k_barcode_static<QSG_%d>, grid, dim3(PK_WAVES * 64), 0, stream, a); break;\n" % (kid, kid))
         fh.write("    default: break;\n    }\n}\n\n")
+        fh.write("// every group of a SMALL batch in one launch (packed_host.inc: packed_barcode): blockIdx.x % n = the group.  A kit-auto batch launches\n"
+                 "// one kernel per (template, set) group although only the voted kit's groups have jobs, and the runtime's four hardware\n"
+                 "// queues serialise them around the two or three that do.\n"
+                 "__global__ void __launch_bounds__(PK_WAVES * 64, 2)\n"
+                 "k_barcode_multi(StaticBarcodeMulti m) {\n"
+                 "    __shared__ uint8_t qbuf[PK_ROWS * 64];\n"
+                 "    const int i = blockIdx.x % (uint32_t)m.n;      // (interleaved: the workgroups of the groups with jobs are resident side by side)\n"
+                 "    StaticArgs a = m.common;\n"
+                 "    a.gidx = m.gidx[i]; a.chunk_b = m.chunk_b[i];\n"
+                 "    switch (m.kernel[i]) {\n")
+        for kid in range(len(fams)):
+            fh.write("    case %d: barcode_static_core<QSG_%d>(a, qbuf); break;\n" % (kid, kid))
+        fh.write("    default: break;\n    }\n}\n"
+                 "static inline void launch_barcode_multi(dim3 grid, hipStream_t stream, const StaticBarcodeMulti& m) {\n"
+                 "    hipLaunchKernelGGL(k_barcode_multi, grid, dim3(PK_WAVES * 64), 0, stream, m);\n}\n\n")
         # the bit-sliced static-letter kernels are compiled in translation units of their own (bs_static.hip with
         # QCAT_BS_PART = 0..BS_PARTS-1, in parallel with this one): greedy split by number of targets
         parts = [[] for _ in range(BS_PARTS)]
