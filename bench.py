@@ -659,7 +659,7 @@ def api4000(a, hip, lib):
     gdesc = gen.descriptor(qcat_config=cfg, ends=native.ENDS_BOTH)
     gkit = native.NativeKit(gdesc)
     sp = native.SynthParams(seed=a.seed, n_reads=a.reads, insert_len=600, lead_min=5, lead_max=40,
-                            error_rate=a.error_rate, no_adapter_fraction=float(os.environ.get("QCAT_X_NOAD", "0.05")), tpl_5p=1, tpl_3p=0)
+                            error_rate=a.error_rate, no_adapter_fraction=0.05, tpl_5p=1, tpl_3p=0)
     buf = np.zeros(4096, dtype=np.uint8)
     reads = []
     for i in range(a.reads):
