@@ -103,6 +103,7 @@ def parse():
     ap.add_argument("--error-rate", type=float, default=0.08)
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-adapter-fraction", type=float, default=0.05, help="share of the synthetic reads that carry no adapter (their barcode regions are whole 150-base windows)")
     ap.add_argument("--no-host-inclusive", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0,
                     help="CPU time of the oracle sample (cpu_baseline + parity); short by default so that the GPU work is not a\n"
@@ -172,7 +173,7 @@ def main():
     comm = parallel.init_comm(ctx, rank, world, trace=comm_stage if world > 1 else None) if use_comm else None
 
     sp = native.SynthParams(seed=a.seed + 1000003 * rank, n_reads=a.reads, insert_len=600, lead_min=5,
-                            lead_max=40, error_rate=a.error_rate, no_adapter_fraction=0.05,
+                            lead_max=40, error_rate=a.error_rate, no_adapter_fraction=a.no_adapter_fraction,
                             tpl_5p=t5, tpl_3p=t3)
     batch = C.c_void_p()
     hip.check(lib.qcat_batch_synthesize(ctx.handle, kit.handle, C.byref(sp), C.byref(batch)))
@@ -659,7 +660,7 @@ def api4000(a, hip, lib):
     gdesc = gen.descriptor(qcat_config=cfg, ends=native.ENDS_BOTH)
     gkit = native.NativeKit(gdesc)
     sp = native.SynthParams(seed=a.seed, n_reads=a.reads, insert_len=600, lead_min=5, lead_max=40,
-                            error_rate=a.error_rate, no_adapter_fraction=0.05, tpl_5p=1, tpl_3p=0)
+                            error_rate=a.error_rate, no_adapter_fraction=a.no_adapter_fraction, tpl_5p=1, tpl_3p=0)
     buf = np.zeros(4096, dtype=np.uint8)
     reads = []
     for i in range(a.reads):
@@ -728,7 +729,7 @@ def api1(a, hip, lib):
     gen = scanner.factory(mode="epi2me", kit="PBC096")
     gkit = native.NativeKit(gen.descriptor(qcat_config=cfg, ends=native.ENDS_BOTH))
     sp = native.SynthParams(seed=a.seed, n_reads=a.reads, insert_len=600, lead_min=5, lead_max=40,
-                            error_rate=a.error_rate, no_adapter_fraction=0.05, tpl_5p=1, tpl_3p=0)
+                            error_rate=a.error_rate, no_adapter_fraction=a.no_adapter_fraction, tpl_5p=1, tpl_3p=0)
     buf = np.zeros(4096, dtype=np.uint8)
     reads = []
     for i in range(a.reads):
