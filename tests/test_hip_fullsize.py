@@ -323,3 +323,48 @@ def test_detect_middle_one_million_reads_across_interior_paths(monkeypatch):
         check_sample_against_oracle(r, recs, 2000, np.random.default_rng(5))
     finally:
         r.close()
+
+
+def test_detect_middle_two_hundred_thousand_reads_an_eighth_of_them_chimeras(monkeypatch):
+    """The synthetic reads of the 1 M-read test above are single molecules: almost none of them reaches exit status 997 (an
+    adapter in the read's INTERIOR, qcat/scanner_base.py:593-595), which the small golden and fuzz cases carry.  Here every
+    eighth read is two reads joined -- the second one's 5' adapter and barcode sit in the middle of the first one's insert side --
+    so 25 000 interiors hold an adapter and some 2 800 reads come out as 997: every record the same on the three interior paths
+    (bit-sliced on one wave per tile, the two-wave pipeline, the binary16 kernel); 1000 of the 997s, 1000 chimeras and 1000 single
+    reads through the oracle."""
+    det = scanner.factory(kit="NBD103/NBD104", scan_middle_adapter=True)
+    n = 200000
+    r = Resident(det, native.ENDS_BOTH, n + n // 8, 20260931, 0.08)
+    try:
+        single = r.host_reads(range(n + n // 8))
+    finally:
+        r.close()
+    reads = [single[i] + single[n + i // 8] if i % 8 == 0 else single[i] for i in range(n)]
+    desc = det.descriptor(ends=native.ENDS_BOTH)
+    assert desc.scan_middle
+    kit = native.NativeKit(desc)
+    bases, offsets = native.pack_reads(reads)
+    out = {}
+    for name, value in ((None, None), ("QCAT_HIP_MIDDLE_ABS_ONE_WAVE", "0"), ("QCAT_HIP_MIDDLE_NO_ABS", "1")):
+        if name:
+            monkeypatch.setenv(name, value)
+        cnt = np.zeros(desc.n_count_buckets, dtype=np.int64)
+        out[name] = (native.NativeContext(0).scan(kit, bases, offsets, counts=cnt), cnt)
+        if name:
+            monkeypatch.delenv(name)
+    recs, cnt = out[None]
+    for name in list(out)[1:]:
+        diff = np.flatnonzero(out[name][0] != recs)
+        assert diff.size == 0, "%s: %d records differ, first at read %d" % (name, diff.size, diff[0])
+        assert np.array_equal(out[name][1], cnt)
+    is_997 = recs["exit_status"] == 997
+    n_997 = int(np.count_nonzero(is_997))
+    # (the interior scan wants the called kit's adapter AND a barcode at middle_min_score behind it: one chimera in nine passes)
+    assert n_997 >= n // 100, n_997
+    assert np.count_nonzero(is_997[np.arange(n) % 8 != 0]) < n // 200
+    rng = np.random.default_rng(11)
+    idx = np.unique(np.concatenate([rng.choice(np.flatnonzero(is_997), size=1000, replace=False),
+                                    rng.choice(n // 8, size=1000, replace=False) * 8,
+                                    rng.choice(n // 8, size=1000, replace=False) * 8 + 1 + rng.integers(0, 7, size=1000)]))
+    want = oracle_lib.scan(desc, [reads[i] for i in idx], threads=16)
+    assert recs[idx].tobytes() == want.tobytes()
