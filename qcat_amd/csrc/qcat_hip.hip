@@ -517,8 +517,8 @@ struct qcat_ctx {
     uint64_t* hb_offsets = nullptr; uint32_t* hb_len = nullptr; size_t cap_hb_reads = 0;
     unsigned long long* vote_buf = nullptr;        // per batch of a kit vote: MAX_T counters, MAX_T first voters, then one chosen slot each
     size_t cap_vote_batches = 0;
-    // the device work of a kit-auto host-buffer call as a captured graph (scan_batch_auto_impl): ~45 launches on twelve
-    // streams replayed by one hipGraphLaunch when a call has the shape of the one before it
+    // the device work of a kit-auto host-buffer call as a captured graph (scan_batch_auto_impl): two dozen launches (round 5: ~45 on
+    // twelve streams) replayed by one hipGraphLaunch when a call has the shape of the one before it
     struct ApiGraph {
         hipGraphExec_t exec = nullptr;
         uint64_t kit = 0, n_bases = 0, gen = 0; uint32_t n_reads = 0, batch_reads = 0;             // what `exec` was captured for
