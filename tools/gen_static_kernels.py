@@ -274,6 +274,7 @@ def render():
             fh.write("\n")
         reg.sort()
         assert len(set(h for h, _, _, _ in reg)) == len(reg), "hash collision between targets"
+        fh.write("#ifndef QCAT_STATIC_MULTI_TU      // (static_multi.hip takes the column chains above and the merged kernels only)\n")
         fh.write("// (the hash only finds the entry; static_match compares `seq` with the kit's target before binding)\n")
         fh.write("struct StaticTarget { uint64_t hash; int16_t kernel, kase; const char* seq; };\n")
         fh.write("static const StaticTarget g_static_targets[] = {\n")
@@ -296,10 +297,11 @@ def render():
                  "    switch (kernel) {\n")
         for kid in range(len(fams)):
             fh.write("    case %d: hipLaunchKernelGGL(k_barcode_static<QSG_%d>, grid, dim3(PK_WAVES * 64), 0, stream, a); break;\n" % (kid, kid))
-        fh.write("    default: break;\n    }\n}\n\n")
+        fh.write("    default: break;\n    }\n}\n#endif\n\n")
         fh.write("// every group of a SMALL batch in one launch (packed_host.inc: packed_barcode): blockIdx.x % n = the group.  A kit-auto batch launches\n"
                  "// one kernel per (template, set) group although only the voted kit's groups have jobs, and the runtime's four hardware\n"
-                 "// queues serialise them around the two or three that do.\n"
+                 "// queues serialise them around the two or three that do.  Compiled in a translation unit of its own (static_multi.hip).\n"
+                 "#ifdef QCAT_STATIC_MULTI_TU\n"
                  "__global__ void __launch_bounds__(PK_WAVES * 64, 2)\n"
                  "k_barcode_multi(StaticBarcodeMulti m) {\n"
                  "    __shared__ uint8_t qbuf[PK_ROWS * 64];\n"
@@ -310,17 +312,21 @@ def render():
         for kid in range(len(fams)):
             fh.write("    case %d: barcode_static_core<QSG_%d>(a, qbuf); break;\n" % (kid, kid))
         fh.write("    default: break;\n    }\n}\n"
-                 "static inline void launch_barcode_multi(dim3 grid, hipStream_t stream, const StaticBarcodeMulti& m) {\n"
-                 "    hipLaunchKernelGGL(k_barcode_multi, grid, dim3(PK_WAVES * 64), 0, stream, m);\n}\n\n")
+                 "extern \"C\" void qcat_static_multi_barcode(unsigned grid, void* stream, const void* m) {\n"
+                 "    hipLaunchKernelGGL(k_barcode_multi, dim3(grid), dim3(PK_WAVES * 64), 0, static_cast<hipStream_t>(stream), *static_cast<const StaticBarcodeMulti*>(m));\n}\n"
+                 "#else\n"
+                 "extern \"C\" void qcat_static_multi_barcode(unsigned grid, void* stream, const void* m);\n"
+                 "static inline void launch_barcode_multi(dim3 grid, hipStream_t stream, const StaticBarcodeMulti& m) { qcat_static_multi_barcode(grid.x, stream, &m); }\n"
+                 "#endif\n\n")
         # the bit-sliced static-letter kernels are compiled in translation units of their own (bs_static.hip with
         # QCAT_BS_PART = 0..BS_PARTS-1, in parallel with this one): greedy split by number of targets
         parts = [[] for _ in range(BS_PARTS)]
         for kid, nt, text in sorted(bs_structs, key=lambda x: -x[1]):
             min(parts, key=lambda p: sum(n for _, n, _ in p)).append((kid, nt, text))
-        fh.write("}  // namespace qk\n")
+        fh.write("}  // namespace qk\n#ifndef QCAT_STATIC_MULTI_TU\n")
         for p in range(BS_PARTS):
             fh.write('extern "C" void qcat_bs_launch_part%d(int kernel, unsigned grid, void* stream, const void* args);   // bs_static.hip\n' % p)
-        fh.write("namespace qk {\n")
+        fh.write("#endif\nnamespace qk {\n#ifndef QCAT_STATIC_MULTI_TU\n")
         fh.write("static inline void launch_bs_static(int kernel, dim3 grid, hipStream_t stream, const BsArgs& a) {\n"
                  "    if (kernel >= QCAT_JIT_BASE) { jit_launch(QCAT_JIT_BITSLICE, kernel - QCAT_JIT_BASE, grid, stream, &a); return; }\n"
                  "    switch (kernel) {\n")
@@ -328,7 +334,7 @@ def render():
             if part:
                 fh.write("    %s qcat_bs_launch_part%d(kernel, grid.x, stream, &a); break;\n"
                          % (" ".join("case %d:" % kid for kid, _, _ in sorted(part)), p))
-        fh.write("    default: break;\n    }\n}\n\n")
+        fh.write("    default: break;\n    }\n}\n#endif\n\n")
         bparts = ["// GENERATED by tools/gen_static_kernels.py -- do not edit.\n"
                   "// Bit-sliced barcode kernels with the target letters compiled in (kernels_bitslice.inc), one struct per target\n"
                   "// family; compiled by bs_static.hip in %d parts (QCAT_BS_PART), each in its own namespace.\n\n" % BS_PARTS]
@@ -354,7 +360,7 @@ def render():
             areg.append((fnv1a64([ACODE[c] for c in seq]), tid, len(seq), seq))
         areg.sort()
         assert len(set(h for h, _, _, _ in areg)) == len(areg), "hash collision between templates"
-        fh.write("\nstruct StaticTemplate { uint64_t hash; int16_t kernel, len; const char* seq; };\n")
+        fh.write("\n#ifndef QCAT_STATIC_MULTI_TU\nstruct StaticTemplate { uint64_t hash; int16_t kernel, len; const char* seq; };\n")
         fh.write("static const StaticTemplate g_static_templates[] = {\n")
         for h, tid, m, seq in areg:
             fh.write("    {0x%016XULL, %d, %d, \"%s\"},\n" % (h, tid, m, seq))
@@ -365,7 +371,7 @@ def render():
         for tid, seq in enumerate(templates):
             fh.write("    case %d: hipLaunchKernelGGL((k_adapter_static<%d, QAC_%d>), grid, dim3(PK_WAVES * 64), 0, stream, a); break;\n"
                      % (tid, len(seq), tid))
-        fh.write("    default: break;\n    }\n}\n\n")
+        fh.write("    default: break;\n    }\n}\n#endif\n\n")
         # ---- two-template kits: one fused pass ----------------------------------------------------
         for fid, (sa, sb) in enumerate(fused):
             u = len(os.path.commonprefix([sa, sb]))
@@ -377,7 +383,7 @@ def render():
                 fh.write("    static __device__ __forceinline__ void %s(h2 (&h)[%d], h2& carry, h2& left, const h2 (&E)[5]) { %s }\n"
                          % (name, len(q) - u + 1, chain(q[u:], ACODE)))
             fh.write("};\n")
-        fh.write("\n// (tpl_a / tpl_b: the static adapter kernels of the two templates, which static_match has verified)\n")
+        fh.write("\n#ifndef QCAT_STATIC_MULTI_TU\n// (tpl_a / tpl_b: the static adapter kernels of the two templates, which static_match has verified)\n")
         fh.write("struct StaticFused { int16_t tpl_a, tpl_b, kernel; };\n")
         fh.write("static const StaticFused g_static_fused[] = {\n")
         for fid, (sa, sb) in enumerate(fused):
@@ -389,11 +395,12 @@ def render():
             u = len(os.path.commonprefix([sa, sb]))
             fh.write("    case %d: hipLaunchKernelGGL((k_adapter_fused2<%d, %d, %d, QAF_%d>), grid, dim3(PK_WAVES * 64), 0, stream, a); break;\n"
                      % (fid, u, len(sa), len(sb), fid))
-        fh.write("    default: break;\n    }\n}\n\n")
+        fh.write("    default: break;\n    }\n}\n#endif\n\n")
         # ---- every chain of a small batch in one launch ------------------------------------------
         fh.write("// every static-letter adapter chain of a SMALL batch in one launch (packed_host.inc: packed_adapter): blockIdx.y = the unit --\n"
                  "// a template or a fused pair.  The units of such a batch are latency chains (one wave per SIMD, 50-110 us each for the\n"
                  "// 4000 reads of the reference driver's call), and launches of their own are serialised by the runtime's four hardware queues.\n"
+                 "#ifdef QCAT_STATIC_MULTI_TU\n"
                  "__global__ void __launch_bounds__(PK_WAVES * 64, 2)\n"
                  "k_adapter_multi(StaticAdapterMulti m) {\n"
                  "    __shared__ uint8_t qbuf[PK_ROWS * 64];\n"
@@ -411,8 +418,12 @@ def render():
         for tid, seq in enumerate(templates):
             fh.write("        case %d: adapter_static_core<%d, QAC_%d>(a, qbuf, slow_tbl); break;\n" % (tid, len(seq), tid))
         fh.write("        default: break;\n        }\n    }\n}\n"
-                 "static inline void launch_adapter_multi(dim3 grid, hipStream_t stream, const StaticAdapterMulti& m) {\n"
-                 "    hipLaunchKernelGGL(k_adapter_multi, grid, dim3(PK_WAVES * 64), 0, stream, m);\n}\n\n")
+                 "extern \"C\" void qcat_static_multi_adapter(unsigned grid_x, unsigned grid_y, void* stream, const void* m) {\n"
+                 "    hipLaunchKernelGGL(k_adapter_multi, dim3(grid_x, grid_y), dim3(PK_WAVES * 64), 0, static_cast<hipStream_t>(stream), *static_cast<const StaticAdapterMulti*>(m));\n}\n"
+                 "#else\n"
+                 "extern \"C\" void qcat_static_multi_adapter(unsigned grid_x, unsigned grid_y, void* stream, const void* m);\n"
+                 "static inline void launch_adapter_multi(dim3 grid, hipStream_t stream, const StaticAdapterMulti& m) { qcat_static_multi_adapter(grid.x, grid.y, stream, &m); }\n"
+                 "#endif\n\n")
         fh.write("// the same column chains over the read interior (--detect-middle, kernels_middle.inc)\n")
         fh.write("#ifdef QCAT_HAVE_MIDDLE_KERNELS\n")
         fh.write("static inline void launch_adapter_middle(int kernel, dim3 grid, hipStream_t stream, const MiddleAdapterArgs& a) {\n"
