@@ -1277,31 +1277,41 @@ extern "C" int qcat_batch_upload(qcat_ctx* c, const uint8_t* bases, const uint64
 static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t* bases, const uint64_t* offsets,
                                 uint32_t n_reads, qcat_batch** out, const uint8_t* const* ptrs = nullptr, const uint64_t* lens = nullptr) {
     const DevKit& hk = kit->hk.dk;
-    std::vector<uint8_t> cat;
-    std::vector<uint64_t> cat_off;
-    // (round 5: small batches are compacted into the context's own staging like big ones -- a fresh pair of device buffers per
-    //  call, as before, was two hipMalloc / hipFree and a synchronisation in every single-read call)
-    if (ptrs && (hk.scan_middle || opt_on(QO_FULL_UPLOAD))) {      // the paths that take whole reads: concatenate
-        cat_off.resize((size_t)n_reads + 1);
+    // the paths that take WHOLE reads (--detect-middle: the interior scan; QCAT_HIP_FULL_UPLOAD): round 6 -- through the same pinned
+    // staging, host threads and context-owned device buffers as the windows (a read is "compacted" to all of itself).  Before,
+    // they were concatenated by one thread into pageable memory and went through qcat_batch_upload: a hipMalloc / hipFree and a
+    // pageable copy per call -- 21 ms per 173 000-read segment of the driver's file loop, whose scan takes 1 ms.  Batches
+    // of more than a gigabyte keep the plain upload (the staging is pinned memory and stays with the context).
+    const bool whole = hk.scan_middle || opt_on(QO_FULL_UPLOAD);
+    if (whole && c && (ptrs || offsets)) {
         uint64_t tot = 0;
-        for (uint32_t r = 0; r < n_reads; ++r) {
-            if (lens[r] && !ptrs[r]) return set_err(QCAT_ERR_ARG, "null read pointer");
-            if (lens[r] > 0xFFFFFFFFull) return set_err(QCAT_ERR_UNSUPPORTED, "read longer than 4 Gb");
-            cat_off[r] = tot; tot += lens[r];
+        if (ptrs) for (uint32_t r = 0; r < n_reads; ++r) tot += lens[r];
+        else tot = offsets[n_reads];
+        if (tot > (1ull << 30)) {
+            std::vector<uint8_t> cat;
+            std::vector<uint64_t> cat_off;
+            if (ptrs) {
+                cat_off.resize((size_t)n_reads + 1);
+                tot = 0;
+                for (uint32_t r = 0; r < n_reads; ++r) {
+                    if (lens[r] && !ptrs[r]) return set_err(QCAT_ERR_ARG, "null read pointer");
+                    if (lens[r] > 0xFFFFFFFFull) return set_err(QCAT_ERR_UNSUPPORTED, "read longer than 4 Gb");
+                    cat_off[r] = tot; tot += lens[r];
+                }
+                cat_off[n_reads] = tot;
+                cat.resize((size_t)tot + 1);
+                for (uint32_t r = 0; r < n_reads; ++r) if (lens[r]) memcpy(cat.data() + cat_off[r], ptrs[r], (size_t)lens[r]);
+                bases = cat.data(); offsets = cat_off.data();
+            }
+            return qcat_batch_upload(c, bases, offsets, n_reads, out);
         }
-        cat_off[n_reads] = tot;
-        cat.resize((size_t)tot + 1);
-        for (uint32_t r = 0; r < n_reads; ++r) if (lens[r]) memcpy(cat.data() + cat_off[r], ptrs[r], (size_t)lens[r]);
-        bases = cat.data(); offsets = cat_off.data(); ptrs = nullptr;
     }
-    if (hk.scan_middle || opt_on(QO_FULL_UPLOAD))
-        return qcat_batch_upload(c, bases, offsets, n_reads, out);
     if (!c || !out || (!ptrs && (!offsets || (!bases && offsets[n_reads] > 0)))) return set_err(QCAT_ERR_ARG, "qcat_scan_batch: null argument");
     if (!ptrs && offsets[0] != 0) return set_err(QCAT_ERR_ARG, "offsets[0] must be 0");
     HIPCHK(hipSetDevice(c->device));
     const uint64_t n = (uint64_t)hk.max_align;
     const bool both = hk.ends == QCAT_ENDS_BOTH;
-    const uint64_t keep = both ? 2 * n : n;
+    const uint64_t keep = whole ? ~0ull : (both ? 2 * n : n);
     if ((size_t)n_reads + 1 > c->cap_pin_reads) {
         if (c->pin_offsets) (void)hipHostFree(c->pin_offsets);
         if (c->pin_len) (void)hipHostFree(c->pin_len);
@@ -1332,7 +1342,7 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
     }
     uint8_t* const pin_data = c->pin_bases + BATCH_SLACK;
     {
-        const unsigned nthreads = std::min<unsigned>(host_threads(), std::max<uint32_t>(1u, n_reads / 16384u));
+        const unsigned nthreads = std::min<unsigned>(host_threads(), (unsigned)std::max<uint64_t>(1u, std::max<uint64_t>(n_reads / 16384u, total >> 23)));
         auto work = [&](uint32_t r0, uint32_t r1) {
             for (uint32_t r = r0; r < r1; ++r) {
                 const uint8_t* src = ptrs ? ptrs[r] : bases + offsets[r];
@@ -1376,7 +1386,7 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
     b->device = c->device; b->n_reads = n_reads; b->n_bases = total; b->borrowed = true;
     // a handful of reads (detect_barcode on one read): the kernels read the pinned staging in place -- host memory the device
     // maps at the same address -- instead of waiting for three copies of a few hundred bytes (~4.5 us each in the call's chain)
-    if (n_reads <= 64 && !opt_on(QO_NO_ZERO_COPY)) {
+    if (n_reads <= 64 && !whole && !opt_on(QO_NO_ZERO_COPY)) {
         memset(pin_data + total, 0, 1 + BATCH_SLACK);
         b->bases_alloc = c->pin_bases; b->bases = pin_data; b->offsets = c->pin_offsets; b->true_len = c->pin_len;
         *out = guard.release();
@@ -1758,7 +1768,7 @@ static int api_graph_run(qcat_ctx* c, qcat_ctx::ApiGraph& G, qcat_kit* kit, KitO
     const uint32_t n_reads = b->n_reads;
     auto drained = [&](int code) { (void)hipStreamSynchronize(c->stream); return code; };
     static const QcatOpt no_capture[] = {QO_NO_GRAPH, QO_DEBUG_VOTE, QO_BS_TRACE, QO_DEBUG_BINS, QO_DEBUG_REDO};
-    bool graph_ok = !c->timing && G.failures < 2 && b->borrowed;      // (whole reads -- --detect-middle -- sit in buffers of their own)
+    bool graph_ok = !c->timing && G.failures < 2 && b->borrowed && !kit->hk.dk.scan_middle && !opt_on(QO_FULL_UPLOAD);      // (whole reads -- --detect-middle -- never replay)
     for (QcatOpt o : no_capture) if (opt_on(o)) graph_ok = false;
     const uint64_t gen_before = g_alloc_gen.load();
     bool done = false;
@@ -1800,11 +1810,12 @@ static int api_graph_run(qcat_ctx* c, qcat_ctx::ApiGraph& G, qcat_kit* kit, KitO
     return 0;
 }
 
-extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
-                               const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
-                               qcat_result* out, int64_t* counts,
-                               qcat_end_trace* traces, int16_t* bc_rows, uint32_t row_stride) {
-    if (!c || !ckit || !offsets || !out) return set_err(QCAT_ERR_ARG, "null argument");
+// (ptrs / lens: the reads as one pointer and one length each instead of bases / offsets -- the file loops' one-shot path)
+static int scan_debug_impl(qcat_ctx* c, const qcat_kit* ckit,
+                           const uint8_t* bases, const uint64_t* offsets, const uint8_t* const* ptrs, const uint64_t* lens, uint32_t n_reads,
+                           qcat_result* out, int64_t* counts,
+                           qcat_end_trace* traces, int16_t* bc_rows, uint32_t row_stride) {
+    if (!c || !ckit || (!offsets && !ptrs) || !out) return set_err(QCAT_ERR_ARG, "null argument");
     qcat_kit* kit = const_cast<qcat_kit*>(ckit);
     if (bc_rows) {
         int need = 0;
@@ -1813,10 +1824,11 @@ extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
         if ((int)row_stride < need) return set_err(QCAT_ERR_ARG, "row_stride smaller than the largest barcode set");
     }
     qcat_batch* b = nullptr;
-    int rc = batch_upload_windows(c, kit, bases, offsets, n_reads, &b);
+    int rc = batch_upload_windows(c, kit, bases, offsets, n_reads, &b, ptrs, lens);
     if (rc) return rc;
     const bool debug = traces != nullptr || bc_rows != nullptr;
-    if (!debug && b->borrowed && n_reads && n_reads <= 65536) {
+    // (whole reads -- --detect-middle -- never replay a graph: the interior scan sizes buffers from the batch)
+    if (!debug && b->borrowed && n_reads && n_reads <= 65536 && !kit->hk.dk.scan_middle && !opt_on(QO_FULL_UPLOAD)) {
         // the reference's library entry -- detect_barcode / detect_barcode_batch with a named kit, down to ONE read per call
         // (qcat/test/test_barcode.py:84, cli.py:504-509) -- is a dozen launches of a few microseconds each: calls of one shape
         // replay them as a graph, like the kit-auto calls (api_graph_run)
@@ -1843,6 +1855,14 @@ extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
     }
     qcat_batch_destroy(b);
     return rc;
+}
+
+extern "C" int qcat_scan_debug(qcat_ctx* c, const qcat_kit* ckit,
+                               const uint8_t* bases, const uint64_t* offsets, uint32_t n_reads,
+                               qcat_result* out, int64_t* counts,
+                               qcat_end_trace* traces, int16_t* bc_rows, uint32_t row_stride) {
+    if (!offsets) return set_err(QCAT_ERR_ARG, "null argument");
+    return scan_debug_impl(c, ckit, bases, offsets, nullptr, nullptr, n_reads, out, counts, traces, bc_rows, row_stride);
 }
 
 // the vote's device buffer for nb batches: votes [nb][MAX_T], first voters [nb][MAX_T], chosen slots [nb]
