@@ -40,15 +40,15 @@ with open(big, "wb", buffering=32 << 20) as fh:
         fh.write(b"\n")
 print("file: %.2f GB, %d reads" % (os.path.getsize(big) / 1e9, n))
 cfg = config.get_default_config()
-for middle in (False, True):
-    det = scanner.factory(kit="PBC096", scan_middle_adapter=middle)
+for middle in (False, True, "auto"):
+    det = scanner.factory(kit=None) if middle == "auto" else scanner.factory(kit="PBC096", scan_middle_adapter=middle)
     kit = det._native_kit(det.layouts, cfg, native.ENDS_BOTH)
     for rep in range(3):
         sink = tempfile.TemporaryFile()
         t0 = time.perf_counter()
-        st = native.FastqFile.demux_stream(big, det._context(), kit, det.layouts, False, kit_auto=False, trim=True, min_read_length=100,
+        st = native.FastqFile.demux_stream(big, det._context(), kit, det.layouts, False, kit_auto=(middle == "auto"), trim=True, min_read_length=100,
                                            tsv_fd=sink.fileno(), out_fd=None, out_dir=None)[4]
         dt = time.perf_counter() - t0
         sink.close()
-        print("detect-middle %d run %d: %.3f s = %.1f M reads/s; busy: parse %.3f scan %.3f write %.3f; %d segments" % (
+        print("detect-middle %s run %d: %.3f s = %.1f M reads/s; busy: parse %.3f scan %.3f write %.3f; %d segments" % (
             middle, rep, dt, n / dt / 1e6, st["parse_s"], st["scan_s"], st["write_s"], st["segments"]), flush=True)
