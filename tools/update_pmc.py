@@ -21,11 +21,11 @@ MARKS = [
     ("k_mid_windows", "k_middle_packed"), ("k_adapter_middle", "k_middle_packed"), ("k_middle", "k_middle_packed"), ("k_mid_", "k_middle_packed"),
     ("k_adapter_finish", "k_job_sort"),                 # (launched after the adapter phase's mark: its time is in the next one)
     ("k_abs_", "k_adapter_static"), ("k_adapter_bs", "k_adapter_static"), ("k_adapter_ms", "k_adapter_static"), ("k_adapter_mw", "k_adapter_static"),
-    ("k_adapter_fused2", "k_adapter_static"), ("k_adapter_static", "k_adapter_static"),
+    ("k_adapter_fused2", "k_adapter_static"), ("k_adapter_static", "k_adapter_static"), ("k_adapter_multi", "k_adapter_static"),
     ("k_adapter_packed", "k_adapter_packed"),
     ("k_job_", "k_job_sort"), ("k_bs_plan", "k_job_sort"),
     ("k_bs_", "k_barcode_bitslice"),
-    ("k_barcode_static", "k_barcode_static"), ("k_barcode_packed", "k_barcode_packed"),
+    ("k_barcode_static", "k_barcode_static"), ("k_barcode_multi", "k_barcode_static"), ("k_barcode_packed", "k_barcode_packed"),
     ("k_barcode_select", "k_barcode_select"), ("k_barcode_redo", "k_barcode_select"),
     ("k_finalize", "k_finalize"),
 ]
