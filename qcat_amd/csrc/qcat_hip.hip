@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <cctype>
 #include <chrono>
 #include <cstdio>
@@ -1341,32 +1342,6 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
         g_alloc_gen.fetch_add(1);
     }
     uint8_t* const pin_data = c->pin_bases + BATCH_SLACK;
-    {
-        const unsigned nthreads = std::min<unsigned>(host_threads(), (unsigned)std::max<uint64_t>(1u, std::max<uint64_t>(n_reads / 16384u, total >> 23)));
-        auto work = [&](uint32_t r0, uint32_t r1) {
-            for (uint32_t r = r0; r < r1; ++r) {
-                const uint8_t* src = ptrs ? ptrs[r] : bases + offsets[r];
-                const uint64_t len = ptrs ? lens[r] : offsets[r + 1] - offsets[r];
-                uint8_t* dst = pin_data + c->pin_offsets[r];
-                if (len <= keep) { memcpy(dst, src, len); continue; }
-                memcpy(dst, src, n);
-                if (both) memcpy(dst + n, src + len - n, n);
-            }
-        };
-        std::vector<std::thread> pool;
-        const uint32_t per = (n_reads + nthreads - 1) / nthreads;
-        uint32_t done_to = std::min<uint32_t>(n_reads, per);          // [0, per) is this thread's share
-        for (unsigned t = 1; t < nthreads; ++t) {
-            const uint32_t r0 = std::min<uint32_t>(n_reads, t * per), r1 = std::min<uint32_t>(n_reads, r0 + per);
-            if (r0 >= r1) break;
-            try { pool.emplace_back(work, r0, r1); }
-            catch (const std::exception&) { break; }                 // no more threads: the rest runs here
-            done_to = r1;
-        }
-        work(0, std::min<uint32_t>(n_reads, per));
-        if (done_to < n_reads) work(done_to, n_reads);
-        for (auto& th : pool) th.join();
-    }
     // the context's own device staging (the batch is a view of it: one host-buffer call at a time per context)
     if (total + 2 * BATCH_SLACK > c->cap_hb_bases) {
         (void)hipFree(c->hb_bases); c->hb_bases = nullptr; c->cap_hb_bases = 0;
@@ -1381,19 +1356,90 @@ static int batch_upload_windows(qcat_ctx* c, const qcat_kit* kit, const uint8_t*
             return set_err(QCAT_ERR_NOMEM, "hipMalloc failed for batch");
         c->cap_hb_reads = want;
     }
+    uint8_t* const dev_data = c->hb_bases + BATCH_SLACK;
+    bool sent = false;                                   // the bases have gone to the device slice by slice
+    {
+        const unsigned nthreads = std::min<unsigned>(host_threads(), (unsigned)std::max<uint64_t>(1u, std::max<uint64_t>(n_reads / 16384u, total >> 23)));
+        auto work = [&](uint32_t r0, uint32_t r1) {
+            for (uint32_t r = r0; r < r1; ++r) {
+                const uint8_t* src = ptrs ? ptrs[r] : bases + offsets[r];
+                const uint64_t len = ptrs ? lens[r] : offsets[r + 1] - offsets[r];
+                uint8_t* dst = pin_data + c->pin_offsets[r];
+                if (len <= keep) { memcpy(dst, src, len); continue; }
+                memcpy(dst, src, n);
+                if (both) memcpy(dst + n, src + len - n, n);
+            }
+        };
+        std::vector<std::thread> pool;
+        // a big staging (round 6: whole reads of --detect-middle are 130 MB per segment of the file loop) in slices of ~8 MB that
+        // the workers draw from a counter: this thread sends every finished run of slices on while the others are still being
+        // copied -- the transfer hides behind the compaction instead of following it
+        const uint64_t slice_bytes = 8ull << 20;
+        if (nthreads >= 2 && total >= 4 * slice_bytes) {
+            std::vector<uint32_t> bound;                 // slice j = reads [bound[j], bound[j + 1])
+            bound.push_back(0);
+            for (uint64_t at = slice_bytes; at < total; at += slice_bytes) {
+                const uint32_t r = (uint32_t)(std::lower_bound(c->pin_offsets, c->pin_offsets + n_reads, at) - c->pin_offsets);
+                if (r > bound.back() && r < n_reads) bound.push_back(r);
+            }
+            bound.push_back(n_reads);
+            const size_t n_slices = bound.size() - 1;
+            std::unique_ptr<std::atomic<uint8_t>[]> done(new std::atomic<uint8_t>[n_slices]);
+            for (size_t j = 0; j < n_slices; ++j) done[j].store(0, std::memory_order_relaxed);
+            std::atomic<size_t> next{0};
+            auto drain = [&] {
+                for (;;) {
+                    const size_t j = next.fetch_add(1);
+                    if (j >= n_slices) break;
+                    work(bound[j], bound[j + 1]);
+                    done[j].store(1, std::memory_order_release);
+                }
+            };
+            for (unsigned t = 0; t < nthreads; ++t) {
+                try { pool.emplace_back(drain); }
+                catch (const std::exception&) { break; }
+            }
+            if (pool.empty()) drain();
+            hipError_t ce = hipSuccess;
+            for (size_t j = 0; j < n_slices && ce == hipSuccess; ) {
+                while (!done[j].load(std::memory_order_acquire)) std::this_thread::yield();
+                size_t k = j + 1;
+                while (k < n_slices && done[k].load(std::memory_order_acquire)) ++k;
+                const uint64_t o0 = c->pin_offsets[bound[j]], o1 = c->pin_offsets[bound[k]];
+                if (o1 > o0) ce = hipMemcpyAsync(dev_data + o0, pin_data + o0, o1 - o0, hipMemcpyHostToDevice, c->stream);
+                j = k;
+            }
+            for (auto& th : pool) th.join();
+            if (ce != hipSuccess) { (void)hipStreamSynchronize(c->stream); return set_err(QCAT_ERR_DEVICE, std::string("upload: ") + hipGetErrorString(ce)); }
+            sent = true;
+        } else {
+            const uint32_t per = (n_reads + nthreads - 1) / nthreads;
+            uint32_t done_to = std::min<uint32_t>(n_reads, per);          // [0, per) is this thread's share
+            for (unsigned t = 1; t < nthreads; ++t) {
+                const uint32_t r0 = std::min<uint32_t>(n_reads, t * per), r1 = std::min<uint32_t>(n_reads, r0 + per);
+                if (r0 >= r1) break;
+                try { pool.emplace_back(work, r0, r1); }
+                catch (const std::exception&) { break; }                 // no more threads: the rest runs here
+                done_to = r1;
+            }
+            work(0, std::min<uint32_t>(n_reads, per));
+            if (done_to < n_reads) work(done_to, n_reads);
+            for (auto& th : pool) th.join();
+        }
+    }
     qcat_batch* b = new qcat_batch();
     BatchGuard guard(b);
     b->device = c->device; b->n_reads = n_reads; b->n_bases = total; b->borrowed = true;
     // a handful of reads (detect_barcode on one read): the kernels read the pinned staging in place -- host memory the device
     // maps at the same address -- instead of waiting for three copies of a few hundred bytes (~4.5 us each in the call's chain)
-    if (n_reads <= 64 && !whole && !opt_on(QO_NO_ZERO_COPY)) {
+    if (n_reads <= 64 && !whole && !sent && !opt_on(QO_NO_ZERO_COPY)) {
         memset(pin_data + total, 0, 1 + BATCH_SLACK);
         b->bases_alloc = c->pin_bases; b->bases = pin_data; b->offsets = c->pin_offsets; b->true_len = c->pin_len;
         *out = guard.release();
         return 0;
     }
-    b->bases_alloc = c->hb_bases; b->bases = c->hb_bases + BATCH_SLACK; b->offsets = c->hb_offsets; b->true_len = c->hb_len;
-    if (total) HIPCHK(hipMemcpyAsync(b->bases, pin_data, total, hipMemcpyHostToDevice, c->stream));
+    b->bases_alloc = c->hb_bases; b->bases = dev_data; b->offsets = c->hb_offsets; b->true_len = c->hb_len;
+    if (total && !sent) HIPCHK(hipMemcpyAsync(b->bases, pin_data, total, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b->offsets, c->pin_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(b->true_len, c->pin_len, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream));
     // (no synchronisation here: every caller hands results back to the host and drains the stream for that before it returns,
