@@ -24,7 +24,7 @@
     X(BARCODE_U16, "1 at kit creation: u16 lanes instead of exact-integer binary16 for the barcode tables") \
     X(NO_BITSLICE, "1: every barcode alignment on the binary16 kernels") \
     X(NO_BS_STATIC, "1: bit-sliced barcode kernels with the letters from memory") \
-    X(BITSLICE_MIN, "barcode alignments from which the bit-sliced path is taken (default: 70 000 + 3 500 000 / barcodes)") \
+    X(BITSLICE_MIN, "barcode alignments from which the bit-sliced path is taken (default: 40 000 + 1 900 000 / barcodes; dual kits 70 000 + 3 500 000 / barcodes)") \
     X(BITSLICE_PAD, "jobs from which the rest of a hot class becomes a padded super-tile (0 / unset: never)") \
     X(BS_NO_SOLO, "1: no producer waves for the shared columns") \
     X(BS_NO_SHORT, "1: regions a few bases short of nominal stay on the binary16 kernels (no front-padded units)") \

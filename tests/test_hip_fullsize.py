@@ -165,7 +165,7 @@ def test_config2_one_million_reads_5p_only(monkeypatch):
 
 def test_medium_batch_takes_the_bit_sliced_barcode_kernels_by_default(monkeypatch):
     """120 k PBC096 reads = 240 k jobs: above the point where the bit-sliced barcode kernels pay for a 96-barcode set
-    (70 000 + 3 500 000 / 96 jobs), far below a super-tile per CU -- the batch size of the host pipeline's chunks.  The
+    (round 6: 40 000 + 1 900 000 / 96 jobs), far below a super-tile per CU -- the batch size of the host pipeline's chunks.  The
     default path must take them, and every record must equal the binary16 and the general kernels' (+ an oracle sample)."""
     det = scanner.factory(kit="PBC096")
     r = Resident(det, native.ENDS_BOTH, 120000, 20261001, 0.08)
