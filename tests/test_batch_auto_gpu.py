@@ -248,12 +248,12 @@ def test_several_batches_in_one_call_vote_one_by_one():
     assert len(slots1) == 1 and slots1[0] == slots[0] and np.array_equal(recs1, recs[:1500])
 
 
-@pytest.mark.parametrize("kit,n", [(None, 2500), ("NBD103/NBD104", 2500), ("RAB204", 900), (None, 20000)])
+@pytest.mark.parametrize("kit,n", [(None, 2500), ("NBD103/NBD104", 2500), ("RAB204", 900), (None, 20000), (None, 36000)])
 def test_adapter_chains_of_a_small_batch_in_one_launch(kit, n, hip_options):
     """Round 6: the static-letter adapter chains of a small batch -- nine launches for the twelve auto-detect templates -- leave as
     ONE launch whose blockIdx.y picks the chain (csrc/static_generated.inc: k_adapter_multi).  Records, counts, every template's
     raw score and end (the traces) and every barcode row: identical to launches of their own (QCAT_HIP_NO_ADAPTER_MULTI=1) and to
-    the oracle; 20 000 reads are beyond the switch and take their own launches either way.  The same for the barcode groups
+    the oracle; 36 000 reads are beyond the switch (four waves per SIMD over all chains) and take their own launches either way.  The same for the barcode groups
     (k_barcode_multi, QCAT_HIP_NO_BARCODE_MULTI=1)."""
     det = scanner.factory(kit=kit)
     cfg = config.qcatConfig()
